@@ -1,0 +1,194 @@
+/*
+ * vithip.h — C ABI of libvithip.so, the MI355X (gfx950) backend that replaces the
+ * device side of LimpBunion22/VIT-FPGA's `fpga::net_fpga`.
+ *
+ * The reference has no FFI layer of its own: `src/netFPGA.cpp` talks to OpenCL
+ * directly.  Every entry point below therefore cites the reference *call site*
+ * (file:line under /root/reference) whose job it takes over.  Signatures carry only
+ * plain pointers, sizes and PODs (no HIP, torch or C++ types) so the header is usable
+ * from C, from plain g++ (host/netHIP.cpp), and from ctypes/cgo/JNI style bindings
+ * (INTEGRATION.md shows the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every function returns VH_OK (0) or a VH_ERR_* code; the human-readable reason is
+ *     available through vh_last_error().  Nothing here calls exit(): the reference's
+ *     fatal-on-error convention (aocl_utils::checkError -> cleanup() -> exit,
+ *     netFPGA.cpp:274-278) is re-created, if wanted, by the C++ class above this ABI.
+ *   - "dev" pointers are device (HBM) addresses of the context's GPU, "host" pointers are
+ *     ordinary process memory.  The caller owns every buffer it passes in.
+ *   - a context is not re-entrant; distinct contexts may be used from distinct threads.
+ */
+#ifndef VITHIP_H
+#define VITHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VH_ABI_VERSION 1
+
+/* status codes */
+#define VH_OK 0
+#define VH_ERR_INVALID 1     /* bad argument / shape the kernels do not support       */
+#define VH_ERR_HIP 2         /* a HIP runtime call failed (message has hipGetErrorString) */
+#define VH_ERR_STATE 3       /* call order violated (e.g. forward before weights)     */
+#define VH_ERR_UNSUPPORTED 4 /* valid request that this build does not implement      */
+#define VH_ERR_NO_DEVICE 5   /* no gfx950 device visible                              */
+
+/* arithmetic type of the dense contractions (MFMA operand type; accumulation is fp32) */
+#define VH_DTYPE_BF16 0
+#define VH_DTYPE_FP16 1
+
+/* activation selector of MLP mode.  The reference stores `activations = 1 // RELU2`
+ * (netFPGA.cpp:79) but never defines it (the network_v1 kernel source is absent), so the
+ * numeric codes below are this build's definition; see DESIGN.md "parity unpinned". */
+#define VH_ACT_IDENTITY 0
+#define VH_ACT_RELU2 1    /* min(max(x,0), MAX_RANGE=1)  (def/defines.h:11-12 value range) */
+#define VH_ACT_RELU 2
+#define VH_ACT_HARDTANH 3 /* clamp(x, MIN_RANGE=-1, MAX_RANGE=1) */
+#define VH_ACT_GELU 4     /* exact erf GELU */
+
+/* Vision-Transformer shape.  Replaces the role `net::net_data` (def/defines.h:14-23) plays
+ * for the MLP: it is what sizes the device buffers (_init_kernel, netFPGA.cpp:402-441). */
+typedef struct vh_config {
+    int32_t image_size; /* square input side, e.g. 224                     */
+    int32_t patch_size; /* e.g. 16                                         */
+    int32_t channels;   /* 3                                               */
+    int32_t dim;        /* D, hidden size (multiple of 64)                 */
+    int32_t heads;      /* H, dim/heads must be 64                         */
+    int32_t mlp_dim;    /* M (multiple of 64)                              */
+    int32_t layers;     /* L                                               */
+    int32_t classes;    /* C (multiple of 4)                               */
+    int32_t dtype;      /* VH_DTYPE_*                                      */
+    int32_t max_batch;  /* workspace is sized for this many images         */
+    float ln_eps;       /* 1e-6 for the canonical ViT                      */
+    int32_t reserved;   /* must be 0                                       */
+} vh_config;
+
+typedef struct vh_ctx vh_ctx; /* opaque ViT context (device, stream, weights, workspace) */
+typedef struct vh_mlp vh_mlp; /* opaque MLP-mode context (the reference's real semantics)  */
+
+/* ---- library / device ---------------------------------------------------------------- */
+int vh_abi_version(void);
+/* replaces clGetPlatformIDs/clGetDeviceIDs (netFPGA.cpp:371-377) */
+int vh_device_count(int* count);
+/* last error of the calling thread (ctx may be NULL) or of that context */
+const char* vh_last_error(const vh_ctx* ctx);
+
+/* ---- raw device memory helpers (so that bindings need no HIP of their own) ------------ */
+int vh_malloc(int device, size_t nbytes, void** dev_ptr);
+int vh_free(int device, void* dev_ptr);
+int vh_memcpy_h2d(int device, void* dev_dst, const void* host_src, size_t nbytes);
+int vh_memcpy_d2h(int device, void* host_dst, const void* dev_src, size_t nbytes);
+int vh_device_synchronize(int device);
+
+/* ---- ViT context ---------------------------------------------------------------------- */
+/* replaces _init_program + _init_kernel(const char*) (netFPGA.cpp:367-441): device,
+ * stream and every device buffer, sized from the net shape. */
+int vh_create(const vh_config* cfg, int device, vh_ctx** out);
+/* replaces cleanup() + ~net_fpga (netFPGA.cpp:613-651); frees ALL device memory. */
+int vh_destroy(vh_ctx* ctx);
+int vh_get_config(const vh_ctx* ctx, vh_config* out);
+
+/* Weight blob = fp32 tensors in canonical order (DESIGN.md "weight blob") preceded by a
+ * 64-byte header.  Replaces _load_params (netFPGA.cpp:484-515): uploads, converts to the
+ * MFMA operand type, permutes the patch kernel to NHWC order and fuses q|k|v. */
+size_t vh_weight_blob_bytes(const vh_config* cfg);
+int vh_load_weights(vh_ctx* ctx, const void* host_blob, size_t nbytes);
+/* same, blob already resident on this context's GPU (e.g. after an RCCL broadcast) */
+int vh_load_weights_device(vh_ctx* ctx, const void* dev_blob, size_t nbytes);
+/* deterministic synthetic weights generated on the device (generator: DESIGN.md "synthetic
+ * data"); replaces the reference's `random` ctor branch (netFPGA.cpp:82-88) for ViT mode. */
+int vh_init_weights_seeded(vh_ctx* ctx, uint64_t seed);
+/* canonical fp32 blob currently loaded, copied back to the host / to a device buffer
+ * (the inverse direction of the ctor flatten, cf. get_net_data netFPGA.cpp:206-237) */
+int vh_export_weights(vh_ctx* ctx, void* host_blob, size_t nbytes);
+int vh_export_weights_device(vh_ctx* ctx, void* dev_blob, size_t nbytes);
+
+/* The hot path.  Replaces launch_forward's device section (netFPGA.cpp:262-284):
+ * in  = batch x image x image x channels fp32, NHWC, host memory;
+ * out = batch x classes fp32 logits, host memory.  Synchronous, like the blocking read. */
+int vh_forward(vh_ctx* ctx, const float* in_nhwc_host, int batch, float* logits_host);
+/* same with both buffers resident in HBM (zero-copy boundary used by bench.py). Enqueues on
+ * the context's stream and waits for completion. */
+int vh_forward_device(vh_ctx* ctx, const float* in_nhwc_dev, int batch, float* logits_dev);
+/* enqueue only; pair with vh_synchronize().  `steps` back-to-back forwards of the same
+ * buffers are enqueued (the timed region of bench.py). */
+int vh_forward_device_async(vh_ctx* ctx, const float* in_nhwc_dev, int batch,
+                            float* logits_dev, int steps);
+int vh_synchronize(vh_ctx* ctx);
+/* uniform[-1,1) synthetic images written straight into HBM (value range of the reference,
+ * def/defines.h:11-12) */
+int vh_fill_input_seeded(vh_ctx* ctx, uint64_t seed, int batch, float* in_nhwc_dev);
+
+/* observability: replaces forward_performance / get_forward_performance
+ * (netFPGA.cpp:262-264,280-284,603-611).  us = host wall time of the last vh_forward*,
+ * kernel_ms = device time between hip events around the last forward's kernels. */
+int vh_last_forward_us(const vh_ctx* ctx, int64_t* us);
+int vh_last_kernel_ms(vh_ctx* ctx, double* ms);
+/* device time of ONE launch of the dominant GEMM kernel class, averaged over the launches
+ * of the last forward (hip events on the context's stream); used for bench.py's roofline */
+int vh_profile_forward(vh_ctx* ctx, const float* in_nhwc_dev, int batch, float* logits_dev,
+                       double* stage_ms, int n_stage_slots, int* n_stages_written);
+const char* vh_stage_name(int stage_index);
+
+/* debug taps: copy an internal activation of the LAST forward to the host as fp32.
+ * what: 0 = residual stream x [batch*T, D] after the last layer run,
+ *       1 = final-LN'd CLS rows [batch, D]. */
+int vh_debug_read(vh_ctx* ctx, int what, float* host_out, size_t n_floats);
+/* run only the first `n_layers` encoder layers on the next forwards (-1 = all) */
+int vh_debug_set_layers(vh_ctx* ctx, int n_layers);
+
+/* ---- operator-level entry points (device pointers, dtype = VH_DTYPE_*) ----------------- */
+/* Each is the kernel the forward uses, exposed so that parity tests and micro-benchmarks
+ * can drive it alone.  `stream` is a hipStream_t passed as void* (NULL = default stream);
+ * the call returns after the kernel has completed. */
+#define VH_EPI_BIAS 0        /* out16[m,n]  = acc + bias[n]                               */
+#define VH_EPI_BIAS_GELU 1   /* out16[m,n]  = gelu(acc + bias[n])                          */
+#define VH_EPI_BIAS_RESID 2  /* out32[m,n] += acc + bias[n]        (fp32 residual stream)  */
+#define VH_EPI_BIAS_F32 3    /* out32[m,n]  = acc + bias[n]                                */
+#define VH_EPI_PATCH 4       /* out32[row(m),n] = acc + bias[n] + pos[tok(m),n]            */
+/* out = epilogue(A[M,K] * W[N,K]^T); A and W hold `dtype` elements, K contiguous.
+ * aux: EPI_PATCH -> pos-emb fp32 [tokens, N] with aux_i = patches per image.
+ * variant: 0 = auto, 1 = 128x128 tile, 2 = 256x256 tile. */
+int vh_op_gemm(const void* a16_dev, const void* w16_dev, const float* bias_dev, void* out_dev,
+               int64_t M, int N, int K, int epilogue, const float* aux_dev, int aux_i,
+               int dtype, int variant, void* stream);
+/* y16[r,:] = LN(x[r*row_stride : +dim]) * gamma + beta */
+int vh_op_layernorm(const float* x_dev, int64_t rows, int dim, int64_t row_stride,
+                    const float* gamma_dev, const float* beta_dev, float eps, void* out16_dev,
+                    int dtype, void* stream);
+/* qkv16 [batch*tokens, 3*heads*64] (q pre-scaled) -> out16 [batch*tokens, heads*64] */
+int vh_op_attention(const void* qkv16_dev, int batch, int tokens, int heads, void* out16_dev,
+                    int dtype, void* stream);
+/* NHWC fp32 images -> patch matrix [batch*np, patch*patch*channels] in `dtype` */
+int vh_op_im2col(const float* in_nhwc_dev, int batch, int image, int patch, int channels,
+                 void* out16_dev, int dtype, void* stream);
+/* fp32 -> dtype cast of n elements (n multiple of 4) */
+int vh_op_cast(const float* in_dev, void* out16_dev, int64_t n, int dtype, void* stream);
+/* synthetic-data generator on the device: kind 0 = uniform[-1,1), 1 = Irwin-Hall(4) * sigma,
+ * 2 = constant `sigma` */
+int vh_op_fill(float* out_dev, int64_t n, uint64_t seed, uint32_t tensor_id, int kind,
+               float sigma, void* stream);
+
+/* ---- MLP mode: the reference's actual launch_forward semantics -------------------------- */
+/* y_l = act(W_l y_{l-1} + b_l), weights row-major [n_out, n_in] per layer, layers and biases
+ * concatenated exactly as the ctor flattens them (netFPGA.cpp:68-76, 91-106); kernel
+ * argument list of network_v1 (netFPGA.cpp:427-436, 499-502). */
+int vh_mlp_create(int device, int n_ins, int n_layers, const int* n_p_l, int activation,
+                  vh_mlp** out);
+int vh_mlp_load_params(vh_mlp* mlp, const float* params_host, size_t n_params,
+                       const float* bias_host, size_t n_neurons);
+/* n_vec input vectors of n_ins floats -> n_vec output vectors of n_p_l[n_layers-1] floats */
+int vh_mlp_forward(vh_mlp* mlp, const float* inputs_host, int n_vec, float* outputs_host);
+int vh_mlp_last_forward_us(const vh_mlp* mlp, int64_t* us);
+const char* vh_mlp_last_error(const vh_mlp* mlp);
+int vh_mlp_destroy(vh_mlp* mlp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITHIP_H */

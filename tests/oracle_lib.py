@@ -1,0 +1,177 @@
+"""ctypes view of oracle/liboracle.so (TEST INFRASTRUCTURE — the CPU checker).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+
+
+class OracleConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("image_size", "patch_size", "channels", "dim", "heads",
+                                          "mlp_dim", "layers", "classes")] + [("ln_eps", C.c_float)]
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.oracle_mix64.restype = C.c_uint64
+        L.oracle_mix64.argtypes = [C.c_uint64]
+        L.oracle_fill.restype = None
+        L.oracle_fill.argtypes = [fp, C.c_int64, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_float]
+        L.oracle_vit_param_count.restype = C.c_size_t
+        L.oracle_vit_param_count.argtypes = [C.POINTER(OracleConfig)]
+        L.oracle_vit_blob_bytes.restype = C.c_size_t
+        L.oracle_vit_blob_bytes.argtypes = [C.POINTER(OracleConfig)]
+        L.oracle_vit_make_blob.restype = C.c_int
+        L.oracle_vit_make_blob.argtypes = [C.POINTER(OracleConfig), C.c_uint64, C.c_void_p, C.c_size_t]
+        L.oracle_vit_forward.restype = C.c_int
+        L.oracle_vit_forward.argtypes = [C.POINTER(OracleConfig), C.c_void_p, fp, C.c_int, fp, fp,
+                                         C.c_int, C.c_int]
+        L.oracle_linear.restype = None
+        L.oracle_linear.argtypes = [fp, fp, fp, fp, C.c_int64, C.c_int, C.c_int]
+        L.oracle_gelu.restype = None
+        L.oracle_gelu.argtypes = [fp, C.c_int64]
+        L.oracle_layernorm.restype = None
+        L.oracle_layernorm.argtypes = [fp, C.c_int64, C.c_int, fp, fp, C.c_float, fp]
+        L.oracle_attention.restype = None
+        L.oracle_attention.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.oracle_im2col.restype = None
+        L.oracle_im2col.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.oracle_round_bf16.restype = None
+        L.oracle_round_bf16.argtypes = [fp, C.c_int64]
+        L.oracle_round_fp16.restype = None
+        L.oracle_round_fp16.argtypes = [fp, C.c_int64]
+        L.oracle_mlp_forward.restype = C.c_int
+        L.oracle_mlp_forward.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), fp, fp, C.c_int, fp, fp]
+        L.oracle_mlp_random_params.restype = None
+        L.oracle_mlp_random_params.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def cfg_struct(cfg, ln_eps=1e-6):
+    return OracleConfig(cfg["image_size"], cfg["patch_size"], cfg["channels"], cfg["dim"],
+                        cfg["heads"], cfg["mlp_dim"], cfg["layers"], cfg["classes"], ln_eps)
+
+
+def fill(n, seed, tensor_id, kind, sigma=0.0, offset=0.0):
+    out = np.empty(n, dtype=np.float32)
+    lib().oracle_fill(_fp(out), n, seed, tensor_id, kind, sigma, offset)
+    return out
+
+
+def make_blob(cfg, seed, ln_eps=1e-6):
+    c = cfg_struct(cfg, ln_eps)
+    n = lib().oracle_vit_blob_bytes(C.byref(c))
+    blob = np.empty(n, dtype=np.uint8)
+    rc = lib().oracle_vit_make_blob(C.byref(c), seed, blob.ctypes.data, n)
+    assert rc == 0
+    return blob
+
+
+def vit_forward(cfg, blob, images, n_layers=-1, threads=0, want_hidden=False, ln_eps=1e-6):
+    c = cfg_struct(cfg, ln_eps)
+    images = _f32(images)
+    batch = images.shape[0]
+    logits = np.empty((batch, cfg["classes"]), dtype=np.float32)
+    g = cfg["image_size"] // cfg["patch_size"]
+    hidden = np.empty((batch * (1 + g * g), cfg["dim"]), dtype=np.float32) if want_hidden else None
+    rc = lib().oracle_vit_forward(C.byref(c), blob.ctypes.data, _fp(images), batch, _fp(logits),
+                                  _fp(hidden) if want_hidden else None, n_layers, threads)
+    assert rc == 0, rc
+    return (logits, hidden) if want_hidden else logits
+
+
+def linear(a, w, bias=None):
+    a, w = _f32(a), _f32(w)
+    M, K = a.shape
+    N = w.shape[0]
+    out = np.empty((M, N), dtype=np.float32)
+    b = _f32(bias) if bias is not None else None
+    lib().oracle_linear(_fp(a), _fp(w), _fp(b) if b is not None else None, _fp(out), M, N, K)
+    return out
+
+
+def gelu(x):
+    x = _f32(x).copy()
+    lib().oracle_gelu(_fp(x), x.size)
+    return x
+
+
+def layernorm(x, gamma, beta, eps=1e-6):
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().oracle_layernorm(_fp(x), x.shape[0], x.shape[1], _fp(_f32(gamma)), _fp(_f32(beta)), eps, _fp(out))
+    return out
+
+
+def attention(qkv, batch, tokens, heads, dh=64):
+    qkv = _f32(qkv)
+    out = np.empty((batch * tokens, heads * dh), dtype=np.float32)
+    lib().oracle_attention(_fp(qkv), batch, tokens, heads, dh, _fp(out))
+    return out
+
+
+def im2col(images, patch):
+    images = _f32(images)
+    b, s, _, ch = images.shape
+    g = s // patch
+    out = np.empty((b * g * g, patch * patch * ch), dtype=np.float32)
+    lib().oracle_im2col(_fp(images), b, s, patch, ch, _fp(out))
+    return out
+
+
+def round_bf16(x):
+    x = _f32(x).copy()
+    lib().oracle_round_bf16(_fp(x), x.size)
+    return x
+
+
+def round_fp16(x):
+    x = _f32(x).copy()
+    lib().oracle_round_fp16(_fp(x), x.size)
+    return x
+
+
+def mlp_forward(n_ins, n_p_l, params, bias, activation, inputs):
+    npl = (C.c_int * len(n_p_l))(*n_p_l)
+    out = np.empty(n_p_l[-1], dtype=np.float32)
+    rc = lib().oracle_mlp_forward(n_ins, len(n_p_l), npl, _fp(_f32(params)), _fp(_f32(bias)), activation,
+                                  _fp(_f32(inputs)), _fp(out))
+    assert rc == 0
+    return out
+
+
+def mlp_random_params(n_params, n_neurons, seed):
+    p = np.empty(n_params, dtype=np.float32)
+    b = np.empty(n_neurons, dtype=np.float32)
+    lib().oracle_mlp_random_params(_fp(p), n_params, _fp(b), n_neurons, seed)
+    return p, b
