@@ -1,0 +1,247 @@
+"""GPU parity, operator level: every HIP kernel of the hot path, driven alone through the C ABI
+(vh_op_*), against the CPU oracle on the same seeded inputs.
+
+Tolerances (written here, per the north star "within 1e-3 relative fp32" for the end-to-end
+logits; operator outputs are 16-bit so the bound is the 16-bit rounding step):
+  bf16 output: 1 ulp = 2^-8 relative  -> |d| <= 2^-8 |ref| + eps
+  fp16 output: 1 ulp = 2^-11 relative
+  fp32 output of a GEMM with 16-bit-exact inputs: only summation order differs -> 2e-5 * scale
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import vh_synth as S
+
+pytestmark = pytest.mark.gpu
+
+vithip = pytest.importorskip("vithip")
+DT = [vithip.DTYPE_BF16, vithip.DTYPE_FP16]
+ULP = {vithip.DTYPE_BF16: 2.0 ** -8, vithip.DTYPE_FP16: 2.0 ** -11}
+
+
+def rnd16(a, dt):
+    return O.round_bf16(a) if dt == vithip.DTYPE_BF16 else O.round_fp16(a)
+
+
+_KEEP = []
+
+
+def dev(a):
+    """Upload and keep the allocation alive until the test ends (a temporary DeviceBuffer would be
+    freed by its destructor before the kernel that reads it runs)."""
+    b = vithip.DeviceBuffer.from_numpy(a)
+    _KEEP.append(b)
+    return b
+
+
+@pytest.fixture(autouse=True)
+def _release_buffers():
+    yield
+    for b in _KEEP:
+        b.free()
+    _KEEP.clear()
+
+
+def assert_close16(got, ref, dt, extra=0.0):
+    """got is a 16-bit kernel output (as fp32), ref the fp32 oracle value."""
+    tol = ULP[dt] * np.abs(ref) * 1.01 + extra + 1e-30
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), (f"{bad.sum()} / {bad.size} elements outside 1 ulp; worst "
+                           f"{np.abs(got - ref).max():.3e} at ref {ref.flat[np.abs(got - ref).argmax()]:.3e}")
+
+
+def test_fill_matches_numpy_and_oracle_bitwise():
+    n = 100003
+    for kind, sigma, tid in ((0, 0.0, 0x100), (1, 0.02, 7), (1, 0.05, 0x7001)):
+        buf = vithip.DeviceBuffer(n * 4)
+        vithip.op_fill(buf.ptr, n, 12345, tid, kind, sigma)
+        got = buf.to_numpy(np.float32, (n,))
+        assert np.array_equal(got, S.fill(n, 12345, tid, kind, sigma))
+        assert np.array_equal(got, O.fill(n, 12345, tid, kind, sigma))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_cast_is_round_to_nearest_even(dt):
+    x = np.concatenate([S.fill(4096, 1, 1, 0) * 3.0, np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, 65504.0, 1e-8, -1e-8],
+                                                                 dtype=np.float32)])
+    out = vithip.DeviceBuffer(x.size * 2)
+    vithip.op_cast(dev(x).ptr, out.ptr, x.size, dt)
+    got = out.to_numpy(np.uint16, x.shape)
+    assert np.array_equal(got, vithip.to16(x, dt))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("image,patch,batch", [(64, 16, 3), (224, 16, 2), (96, 16, 1), (64, 32, 2)])
+def test_im2col(dt, image, patch, batch):
+    x = S.fill(batch * image * image * 3, 5, 9, 0).reshape(batch, image, image, 3)
+    ref = rnd16(O.im2col(x, patch), dt)
+    out = vithip.DeviceBuffer(ref.size * 2)
+    vithip.op_im2col(dev(x).ptr, batch, image, patch, 3, out.ptr, dt)
+    got = vithip.from16(out.to_numpy(np.uint16, ref.shape), dt)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("rows,dim", [(5, 128), (197, 192), (1001, 768), (64, 1024), (3, 64)])
+def test_layernorm(dt, rows, dim):
+    x = (S.fill(rows * dim, 3, 1, 0) * 2.0 + 0.3).reshape(rows, dim)
+    g = S.fill(dim, 3, 2, 1, 0.05, 1.0)
+    b = S.fill(dim, 3, 3, 1, 0.02, 0.0)
+    ref = O.layernorm(x, g, b, 1e-6)
+    out = vithip.DeviceBuffer(rows * dim * 2)
+    vithip.op_layernorm(dev(x).ptr, rows, dim, dim, dev(g).ptr, dev(b).ptr, 1e-6, out.ptr, dt)
+    got = vithip.from16(out.to_numpy(np.uint16, (rows, dim)), dt)
+    assert_close16(got, ref, dt, extra=2e-6)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_layernorm_strided_rows(dt):
+    # the final LN reads only token 0 of every image: row stride = T*D
+    B, T, D = 4, 17, 128
+    x = S.fill(B * T * D, 4, 1, 0).reshape(B, T, D)
+    g = S.fill(D, 4, 2, 1, 0.05, 1.0)
+    b = S.fill(D, 4, 3, 1, 0.02, 0.0)
+    ref = O.layernorm(x[:, 0, :].copy(), g, b, 1e-6)
+    out = vithip.DeviceBuffer(B * D * 2)
+    vithip.op_layernorm(dev(x).ptr, B, D, T * D, dev(g).ptr, dev(b).ptr, 1e-6, out.ptr, dt)
+    assert_close16(vithip.from16(out.to_numpy(np.uint16, (B, D)), dt), ref, dt, extra=2e-6)
+
+
+GEMM_SHAPES = [  # M, N, K — ragged M, N not a tile multiple, every K class of the forward
+    (197, 576, 192), (394, 192, 768), (51, 40, 128), (256, 256, 64), (300, 1000, 768),
+    (1024, 768, 768), (777, 2304, 768), (512, 768, 3072), (34, 128, 768),
+]
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bias_f32(dt, variant, M, N, K):
+    a = rnd16(S.fill(M * K, 7, 1, 0).reshape(M, K), dt)
+    w = rnd16(S.fill(N * K, 7, 2, 1, 0.05).reshape(N, K), dt)
+    bias = S.fill(N, 7, 3, 1, 0.1)
+    ref = O.linear(a, w, bias)
+    out = vithip.DeviceBuffer(M * N * 4)
+    vithip.op_gemm(dev(vithip.to16(a, dt)).ptr, dev(vithip.to16(w, dt)).ptr, dev(bias).ptr, out.ptr, M, N, K,
+                   vithip.EPI_BIAS_F32, dt, variant=variant)
+    got = out.to_numpy(np.float32, (M, N))
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-5 * scale, np.abs(got - ref).max() / scale
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_integer_exact_asymmetric(dt, variant):
+    # exact small-integer data with an asymmetric W catches any row/col or k-order mix-up bitwise
+    M, N, K = 300, 260, 128
+    rng = np.random.default_rng(0)
+    a = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
+    w = rng.integers(-4, 5, size=(N, K)).astype(np.float32)
+    bias = np.arange(N, dtype=np.float32)
+    ref = a @ w.T + bias
+    out = vithip.DeviceBuffer(M * N * 4)
+    vithip.op_gemm(dev(vithip.to16(a, dt)).ptr, dev(vithip.to16(w, dt)).ptr, dev(bias).ptr, out.ptr, M, N, K,
+                   vithip.EPI_BIAS_F32, dt, variant=variant)
+    assert np.array_equal(out.to_numpy(np.float32, (M, N)), ref)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("epi", ["bias", "gelu", "resid"])
+def test_gemm_epilogues(dt, variant, epi):
+    M, N, K = 333, 320, 192
+    a = rnd16(S.fill(M * K, 8, 1, 0).reshape(M, K), dt)
+    w = rnd16(S.fill(N * K, 8, 2, 1, 0.1).reshape(N, K), dt)
+    bias = S.fill(N, 8, 3, 1, 0.1)
+    lin = O.linear(a, w, bias)
+    A, W, Bv = dev(vithip.to16(a, dt)), dev(vithip.to16(w, dt)), dev(bias)
+    if epi == "resid":
+        x0 = S.fill(M * N, 8, 4, 0).reshape(M, N)
+        out = dev(x0)
+        vithip.op_gemm(A.ptr, W.ptr, Bv.ptr, out.ptr, M, N, K, vithip.EPI_BIAS_RESID, dt, variant=variant)
+        got = out.to_numpy(np.float32, (M, N))
+        ref = x0 + lin
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    else:
+        ref = lin if epi == "bias" else O.gelu(lin)
+        out = vithip.DeviceBuffer(M * N * 2)
+        vithip.op_gemm(A.ptr, W.ptr, Bv.ptr, out.ptr, M, N, K,
+                       vithip.EPI_BIAS if epi == "bias" else vithip.EPI_BIAS_GELU, dt, variant=variant)
+        got = vithip.from16(out.to_numpy(np.uint16, (M, N)), dt)
+        assert_close16(got, ref, dt, extra=3e-5 * np.abs(lin).max())
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_patch_epilogue(dt, variant):
+    # rows of the patch matrix are remapped to token rows 1..NP of each image, + pos-emb
+    B, NP, N, K = 3, 16, 128, 768
+    T = NP + 1
+    a = rnd16(S.fill(B * NP * K, 9, 1, 0).reshape(B * NP, K), dt)
+    w = rnd16(S.fill(N * K, 9, 2, 1, 0.02).reshape(N, K), dt)
+    bias = S.fill(N, 9, 3, 1, 0.02)
+    pos = S.fill(T * N, 9, 4, 1, 0.02).reshape(T, N)
+    lin = O.linear(a, w, bias).reshape(B, NP, N)
+    x = np.full((B, T, N), 7.5, dtype=np.float32)
+    ref = x.copy()
+    ref[:, 1:, :] = lin + pos[None, 1:, :]
+    out = dev(x)
+    vithip.op_gemm(dev(vithip.to16(a, dt)).ptr, dev(vithip.to16(w, dt)).ptr, dev(bias).ptr, out.ptr, B * NP, N, K,
+                   vithip.EPI_PATCH, dt, aux_ptr=dev(pos).ptr, aux_i=NP, variant=variant)
+    got = out.to_numpy(np.float32, (B, T, N))
+    assert np.array_equal(got[:, 0, :], x[:, 0, :])  # CLS rows untouched
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_gemm_rejects_bad_shapes():
+    b = vithip.DeviceBuffer(1 << 16)
+    with pytest.raises(vithip.VhError):
+        vithip.op_gemm(b.ptr, b.ptr, b.ptr, b.ptr, 16, 16, 48, vithip.EPI_BIAS, vithip.DTYPE_BF16)  # K % 64
+    with pytest.raises(vithip.VhError):
+        vithip.op_gemm(b.ptr, b.ptr, b.ptr, b.ptr, 16, 18, 64, vithip.EPI_BIAS, vithip.DTYPE_BF16)  # N % 4
+    with pytest.raises(vithip.VhError):
+        vithip.op_gemm(b.ptr, b.ptr, b.ptr, b.ptr, 0, 16, 64, vithip.EPI_BIAS, vithip.DTYPE_BF16)   # empty
+
+
+ATT_TOL = {vithip.DTYPE_BF16: 1.2e-2, vithip.DTYPE_FP16: 1.5e-3}  # P and O are rounded to 16 bit
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("batch,tokens,heads", [(2, 17, 2), (1, 37, 3), (2, 197, 3), (1, 32, 1), (1, 64, 2),
+                                                (1, 1, 1), (1, 257, 2), (1, 577, 2)])
+def test_attention(dt, batch, tokens, heads):
+    D = heads * 64
+    qkv = rnd16((S.fill(batch * tokens * 3 * D, 10, 1, 0) * 1.5).reshape(batch * tokens, 3 * D), dt)
+    ref = O.attention(qkv, batch, tokens, heads)
+    pre = qkv.copy()
+    pre[:, :D] *= 0.125  # exact: the kernel expects q pre-scaled (folded into Wq at load time)
+    out = vithip.DeviceBuffer(batch * tokens * D * 2)
+    vithip.op_attention(dev(vithip.to16(pre, dt)).ptr, batch, tokens, heads, out.ptr, dt)
+    got = vithip.from16(out.to_numpy(np.uint16, (batch * tokens, D)), dt)
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err <= ATT_TOL[dt], err
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_attention_spiked_scores_force_rescale(dt):
+    # one key row aligned with one query row far above the rest: the running max jumps in a late
+    # tile, exercising the online-softmax rescale of O and l (rule: a rare branch needs its own test)
+    batch, tokens, heads = 1, 197, 1
+    D = 64
+    qkv = (S.fill(tokens * 3 * D, 11, 1, 0) * 0.5).reshape(tokens, 3 * D)
+    qkv[5, :D] = 4.0
+    qkv[170, D:2 * D] = 4.0     # score(5,170) = 64*16/8 = 128 >> others
+    qkv[40, :D] = -3.0
+    qkv[3, D:2 * D] = -3.0      # early spike for query 40, then nothing larger
+    qkv = rnd16(qkv, dt)
+    ref = O.attention(qkv, batch, tokens, heads)
+    pre = qkv.copy()
+    pre[:, :D] *= 0.125
+    out = vithip.DeviceBuffer(tokens * D * 2)
+    vithip.op_attention(dev(vithip.to16(pre, dt)).ptr, batch, tokens, heads, out.ptr, dt)
+    got = vithip.from16(out.to_numpy(np.uint16, (tokens, D)), dt)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.abs(ref).max() <= ATT_TOL[dt]
+    # query 5 attends essentially only to key 170
+    assert np.abs(got[5] - qkv[170, 2 * D:]).max() <= 2 * ULP[dt] * np.abs(qkv[170, 2 * D:]).max() + 1e-6

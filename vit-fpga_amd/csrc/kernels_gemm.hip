@@ -1,0 +1,230 @@
+// kernels_gemm.hip — the dense contraction of the ViT hot path, hand-written for gfx950.
+//
+//   out = epilogue( A[M,K] x W[N,K]^T ),  A/W 16-bit (bf16 or fp16), fp32 accumulate (MFMA)
+//
+// This one kernel family carries 92 % of the forward's FLOPs: patch embedding (conv as GEMM),
+// fused q|k|v projection, attention output projection, fc1 (+GELU) and fc2 (+residual), and
+// the classifier head.  It is what replaces the per-layer body of the reference's
+// `network_v1` task (netFPGA.cpp:275; a_l = act(W_l a_{l-1} + b_l), weights row-major
+// [n_out, n_in], netFPGA.cpp:91-106) for a whole batch of token rows at once.
+//
+// Design (CDNA4):
+//   * tile BM x BN x 64, NW = WM*WN waves of 64 lanes; v_mfma_f32_16x16x32_{bf16,f16}.
+//   * operands staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip),
+//     two LDS stages, one barrier per K-tile: the loads of tile k+1 are in flight while
+//     tile k is multiplied.
+//   * LDS rows are 128 B (64 x 16-bit); 16-B chunks are XOR-swizzled with (row & 7).  The DMA
+//     writes LDS linearly, so the swizzle is applied to the per-lane GLOBAL source address and
+//     again on the ds_read_b128 side (same involution) -> conflict-free fragment reads.
+//   * the MFMA "A" operand is the W fragment and "B" the activation fragment, i.e. the wave
+//     computes the transposed tile.  Each lane then owns 4 CONSECUTIVE output columns of one
+//     row, so every epilogue access is an 8-byte (16-bit out) or 16-byte (fp32) vector.
+//   * epilogues fused: +bias, GELU(erf), fp32 residual read-modify-write, patch-row remap
+//     + position embedding.
+//   * 1-D grid remapped so that the workgroups that share an XCD (blockIdx % 8) walk a
+//     contiguous run of tiles, n fastest: neighbours reuse the same A panel from that XCD's L2.
+//   * ragged M / N: loads clamp the row index, stores are predicated (N % 4 == 0, K % 64 == 0).
+#include "vh_kernels.h"
+
+namespace vh {
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+__global__ void __launch_bounds__(WM* WN * 64)
+gemm_nt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W,
+               const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
+               const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n) {
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    constexpr int NW = WM * WN;
+    constexpr int BK = 64;
+    constexpr int ROWS = BM + BN;
+    constexpr int STAGE_BYTES = ROWS * 128;
+    constexpr int GROUPS_A = BM / 8;          // 1-KiB row groups (8 rows x 128 B) of the A part
+    constexpr int GROUPS = ROWS / 8;
+    constexpr int LOADS = GROUPS / NW;        // DMA instructions per wave per stage
+    constexpr int LOADS_A = GROUPS_A / NW;
+    constexpr int TM = BM / WM, TN = BN / WN; // wave tile
+    constexpr int MI = TM / 16, NI = TN / 16;
+    static_assert(GROUPS % NW == 0 && GROUPS_A % NW == 0, "tile/wave mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- XCD-aware tile assignment (bijective for any grid size) -----------------------
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    // ---- DMA source pointers: lane -> (row, swizzled 16-B chunk) -------------------------
+    const int lr = lane >> 3;                 // row inside the 8-row group
+    const int lc = (lane & 7) ^ lr;           // logical chunk that lands in physical slot lane&7
+    const elem* gsrc[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int gi = i * NW + wave;
+        if (i < LOADS_A) {
+            int row = tile_m * BM + gi * 8 + lr;
+            row = row < M ? row : M - 1;
+            gsrc[i] = A + (int64_t)row * K + lc * 8;
+        } else {
+            int row = tile_n * BN + (gi - GROUPS_A) * 8 + lr;
+            row = row < N ? row : N - 1;
+            gsrc[i] = W + (int64_t)row * K + lc * 8;
+        }
+    }
+    auto issue = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int gi = i * NW + wave;
+            __builtin_amdgcn_global_load_lds(
+                (const void __attribute__((address_space(1)))*)(gsrc[i] + kt * BK),
+                (void __attribute__((address_space(3)))*)(smem + stage * STAGE_BYTES + gi * 1024),
+                16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets ------------------------------------------------------------
+    const int frow = lane & 15, fq = lane >> 4;
+    int offk[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) offk[ks] = frow * 128 + ((((ks << 2) | fq) ^ (frow & 7)) << 4);
+    const int xbase = wm * TM * 128;
+    const int wbase = BM * 128 + wn * TN * 128;
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt landed for every wave; everyone is done reading the other stage
+        if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+        const char* st = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            vec8 xf[MI], wf[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                wf[ni] = *(const vec8*)(st + wbase + ni * 2048 + offk[ks]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + offk[ks]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf[ni], xf[mi], acc[mi][ni]);
+        }
+    }
+
+    // ---- epilogue: lane owns rows m = .. + (lane&15), 4 consecutive columns n = .. + 4*(lane>>4)
+    const int m0 = tile_m * BM + wm * TM + frow;
+    const int n0 = tile_n * BN + wn * TN + fq * 4;
+    f32x4 bv[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + ni * 16;
+        bv[ni] = (n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + mi * 16;
+        if (m >= M) continue;
+        int64_t orow = m;
+        const float* posrow = nullptr;
+        if constexpr (EPI == VH_EPI_PATCH) {
+            const int img = m / aux_i, p = m - img * aux_i;
+            orow = (int64_t)img * (aux_i + 1) + 1 + p;
+            posrow = aux + (int64_t)(1 + p) * N;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + ni * 16;
+            if (n >= N) continue;
+            f32x4 v = acc[mi][ni] + bv[ni];
+            if constexpr (EPI == VH_EPI_BIAS) {
+                *(typename T::vec4*)((elem*)outp + orow * N + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+            } else if constexpr (EPI == VH_EPI_BIAS_GELU) {
+                *(typename T::vec4*)((elem*)outp + orow * N + n) =
+                    pack4<T>(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
+            } else if constexpr (EPI == VH_EPI_BIAS_RESID) {
+                f32x4* p = (f32x4*)((float*)outp + orow * N + n);
+                *p = *p + v;
+            } else if constexpr (EPI == VH_EPI_BIAS_F32) {
+                *(f32x4*)((float*)outp + orow * N + n) = v;
+            } else {  // VH_EPI_PATCH
+                *(f32x4*)((float*)outp + orow * N + n) = v + *(const f32x4*)(posrow + n);
+            }
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
+    const int tiles_m = (int)((g.M + BM - 1) / BM), tiles_n = (g.N + BN - 1) / BN;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+    auto k = gemm_nt_kernel<T, BM, BN, WM, WN, EPI>;
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, s,
+                       (const typename T::elem*)g.a, (const typename T::elem*)g.w, g.bias, g.out,
+                       (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+template <typename T, int EPI>
+static hipError_t launch_tile(const GemmArgs& g, int variant, hipStream_t s) {
+    if (variant == 2) return launch_one<T, 256, 256, 2, 4, EPI>(g, s);
+    return launch_one<T, 128, 128, 2, 2, EPI>(g, s);
+}
+
+template <typename T>
+static hipError_t launch_epi(const GemmArgs& g, int variant, hipStream_t s) {
+    switch (g.epilogue) {
+    case VH_EPI_BIAS: return launch_tile<T, VH_EPI_BIAS>(g, variant, s);
+    case VH_EPI_BIAS_GELU: return launch_tile<T, VH_EPI_BIAS_GELU>(g, variant, s);
+    case VH_EPI_BIAS_RESID: return launch_tile<T, VH_EPI_BIAS_RESID>(g, variant, s);
+    case VH_EPI_BIAS_F32: return launch_tile<T, VH_EPI_BIAS_F32>(g, variant, s);
+    case VH_EPI_PATCH: return launch_tile<T, VH_EPI_PATCH>(g, variant, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+int gemm_pick_variant(int64_t M, int N) {
+    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    return t256 >= 256 ? 2 : 1;  // the 256x256 tile only when it still fills all 256 CUs
+}
+
+const char* gemm_check(const GemmArgs& g) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return "gemm: empty shape";
+    if (g.K % 64) return "gemm: K must be a multiple of 64";
+    if (g.N % 4) return "gemm: N must be a multiple of 4";
+    if (g.M > 0x7fffffff) return "gemm: M too large";
+    if (g.epilogue < 0 || g.epilogue > VH_EPI_PATCH) return "gemm: unknown epilogue";
+    if (g.epilogue == VH_EPI_PATCH && (!g.aux || g.aux_i <= 0)) return "gemm: EPI_PATCH needs pos-emb and patches/image";
+    if (g.dtype != VH_DTYPE_BF16 && g.dtype != VH_DTYPE_FP16) return "gemm: dtype";
+    if (g.variant < 0 || g.variant > 2) return "gemm: variant";
+    if (!g.a || !g.w || !g.bias || !g.out) return "gemm: null pointer";
+    return nullptr;
+}
+
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
+    if (gemm_check(g)) return hipErrorInvalidValue;
+    const int variant = g.variant ? g.variant : gemm_pick_variant(g.M, g.N);
+    return g.dtype == VH_DTYPE_BF16 ? launch_epi<BF16>(g, variant, s) : launch_epi<FP16>(g, variant, s);
+}
+
+}  // namespace vh

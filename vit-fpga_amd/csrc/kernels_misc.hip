@@ -1,0 +1,252 @@
+// kernels_misc.hip — the HBM-bound pieces around the GEMMs (gfx950): LayerNorm, patch
+// gather (im2col + cast), CLS-row initialisation, casts, weight re-layout, the synthetic-data
+// generator and the fp32 dense layer of MLP mode.  All of them move 16 bytes per lane.
+#include "vh_kernels.h"
+
+namespace vh {
+
+// ---- LayerNorm: one wave per row, row kept in registers, fp32 statistics ------------------
+// y[r,:] = (x[r,:] - mean) * rstd * gamma + beta  -> 16-bit.  dim % 4 == 0, dim <= 1024*?.
+template <typename T, int CH>  // CH = float4 chunks per lane (dim <= 256*CH)
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const float* __restrict__ x, int64_t rows, int dim, int64_t row_stride,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                 typename T::elem* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = dim >> 2;
+    const f32x4* xr = (const f32x4*)(x + row * row_stride);
+    f32x4 v[CH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nchunk ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)dim;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; var += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)dim + eps);
+    typename T::elem* orow = out + row * dim;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const f32x4 gm = ((const f32x4*)gamma)[c], bt = ((const f32x4*)beta)[c];
+            *(typename T::vec4*)(orow + 4 * c) =
+                pack4<T>((v[i][0] - mean) * rstd * gm[0] + bt[0], (v[i][1] - mean) * rstd * gm[1] + bt[1],
+                         (v[i][2] - mean) * rstd * gm[2] + bt[2], (v[i][3] - mean) * rstd * gm[3] + bt[3]);
+        }
+    }
+}
+
+template <typename T>
+static hipError_t ln_t(const float* x, int64_t rows, int dim, int64_t stride, const float* g, const float* b,
+                       float eps, void* out, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    auto o = (typename T::elem*)out;
+    if (dim <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, s, x, rows, dim, stride, g, b, eps, o);
+    else if (dim <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, s, x, rows, dim, stride, g, b, eps, o);
+    else if (dim <= 768) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, s, x, rows, dim, stride, g, b, eps, o);
+    else if (dim <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, s, x, rows, dim, stride, g, b, eps, o);
+    else if (dim <= 2048) hipLaunchKernelGGL((layernorm_kernel<T, 8>), grid, block, 0, s, x, rows, dim, stride, g, b, eps, o);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* x, int64_t rows, int dim, int64_t row_stride, const float* gamma,
+                            const float* beta, float eps, void* out16, int dtype, hipStream_t s) {
+    if (rows <= 0 || dim <= 0 || (dim & 3) || (row_stride & 3)) return hipErrorInvalidValue;
+    return dtype == VH_DTYPE_BF16 ? ln_t<BF16>(x, rows, dim, row_stride, gamma, beta, eps, out16, s)
+                                  : ln_t<FP16>(x, rows, dim, row_stride, gamma, beta, eps, out16, s);
+}
+
+// ---- im2col + cast: NHWC fp32 image -> patch matrix [batch*np, patch*patch*ch] 16-bit -------
+// one float4 per thread; a patch row is `patch*ch` contiguous floats of the image, and lands as
+// `patch*ch` contiguous 16-bit elements of the patch matrix, so both sides are coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256)
+im2col_kernel(const float* __restrict__ in, typename T::elem* __restrict__ out, int64_t n4, int image,
+              int patch, int ch) {
+    const int rowf4 = image * ch / 4;      // float4 per image row
+    const int prf4 = patch * ch / 4;       // float4 per patch row
+    const int g = image / patch;
+    const int kp = patch * patch * ch;
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < n4; f += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t rowidx = f / rowf4;  // b*image + y
+        const int q = (int)(f - rowidx * rowf4);
+        const int64_t b = rowidx / image;
+        const int y = (int)(rowidx - b * image);
+        const int px = q / prf4, r = q - px * prf4;
+        const int py = y / patch, ky = y - py * patch;
+        const f32x4 v = ((const f32x4*)in)[f];
+        const int64_t orow = (b * g + py) * g + px;
+        *(typename T::vec4*)(out + orow * kp + ky * patch * ch + r * 4) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+}
+
+hipError_t launch_im2col(const float* in, int batch, int image, int patch, int channels, void* out16, int dtype,
+                         hipStream_t s) {
+    if ((patch * channels) % 4 || image % patch) return hipErrorInvalidValue;
+    const int64_t n4 = (int64_t)batch * image * image * channels / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    if (dtype == VH_DTYPE_BF16)
+        hipLaunchKernelGGL(im2col_kernel<BF16>, dim3(grid), dim3(256), 0, s, in, (BF16::elem*)out16, n4, image, patch, channels);
+    else
+        hipLaunchKernelGGL(im2col_kernel<FP16>, dim3(grid), dim3(256), 0, s, in, (FP16::elem*)out16, n4, image, patch, channels);
+    return hipGetLastError();
+}
+
+// ---- x[b, 0, :] = cls + pos[0] ------------------------------------------------------------------
+__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                                int batch, int tokens, int dim) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)batch * dim) return;
+    const int b = (int)(i / dim), d = (int)(i - (int64_t)b * dim);
+    x[(int64_t)b * tokens * dim + d] = cls[d] + pos[d];
+}
+hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int batch, int tokens, int dim, hipStream_t s) {
+    const int64_t n = (int64_t)batch * dim;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, cls, pos, batch, tokens, dim);
+    return hipGetLastError();
+}
+
+// ---- fp32 -> 16-bit cast -----------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) cast_kernel(const float* __restrict__ in, typename T::elem* __restrict__ out, int64_t n4) {
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < n4; f += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = ((const f32x4*)in)[f];
+        ((typename T::vec4*)out)[f] = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+}
+hipError_t launch_cast(const float* in, void* out16, int64_t n, int dtype, hipStream_t s) {
+    if (n <= 0 || (n & 3)) return hipErrorInvalidValue;
+    const int64_t n4 = n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    if (dtype == VH_DTYPE_BF16) hipLaunchKernelGGL(cast_kernel<BF16>, dim3(grid), dim3(256), 0, s, in, (BF16::elem*)out16, n4);
+    else hipLaunchKernelGGL(cast_kernel<FP16>, dim3(grid), dim3(256), 0, s, in, (FP16::elem*)out16, n4);
+    return hipGetLastError();
+}
+
+// ---- synthetic data ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ out, int64_t n, uint64_t stream, int kind,
+                                                   double scale, float offset) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (kind == 0) v = rng_uniform(stream, (uint64_t)i);
+        else if (kind == 1) v = rng_ih4(stream, (uint64_t)i, scale, offset);
+        else v = offset;
+        out[i] = v;
+    }
+}
+hipError_t launch_fill(float* out, int64_t n, uint64_t seed, uint32_t tensor_id, int kind, float sigma, float offset,
+                       hipStream_t s) {
+    if (n <= 0) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, s, out, n, rng_stream(seed, tensor_id), kind,
+                       (double)sigma / kIH4Std, offset);
+    return hipGetLastError();
+}
+
+// ---- weight re-layout ---------------------------------------------------------------------------
+// Wqkv[3D, D] = [q * q_scale ; k ; v] (16-bit), bqkv[3D] = [bq * q_scale ; bk ; bv] (fp32).
+// q_scale = 64^-1/2 = 0.125 is a power of two, so folding it into the weights is exact.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_qkv_kernel(const float* __restrict__ qw, const float* __restrict__ qb, const float* __restrict__ kw,
+                const float* __restrict__ kb, const float* __restrict__ vw, const float* __restrict__ vb, int dim,
+                float q_scale, typename T::elem* __restrict__ w16, float* __restrict__ b32) {
+    const int64_t dd = (int64_t)dim * dim;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * dd) {
+        const int which = (int)(i / dd);
+        const int64_t j = i - which * dd;
+        const float v = which == 0 ? qw[j] * q_scale : (which == 1 ? kw[j] : vw[j]);
+        w16[i] = (typename T::elem)v;
+    }
+    if (i < 3 * dim) {
+        const int which = (int)(i / dim), j = (int)(i - (int64_t)which * dim);
+        b32[i] = which == 0 ? qb[j] * q_scale : (which == 1 ? kb[j] : vb[j]);
+    }
+}
+hipError_t launch_pack_qkv(const float* qw, const float* qb, const float* kw, const float* kb, const float* vw,
+                           const float* vb, int dim, float q_scale, void* w16, float* b32, int dtype, hipStream_t s) {
+    const int64_t n = 3 * (int64_t)dim * dim;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == VH_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_qkv_kernel<BF16>, grid, block, 0, s, qw, qb, kw, kb, vw, vb, dim, q_scale, (BF16::elem*)w16, b32);
+    else
+        hipLaunchKernelGGL(pack_qkv_kernel<FP16>, grid, block, 0, s, qw, qb, kw, kb, vw, vb, dim, q_scale, (FP16::elem*)w16, b32);
+    return hipGetLastError();
+}
+
+// conv kernel [D][c][ky][kx] fp32 -> [D][(ky*P + kx)*C + c] 16-bit: the k-order of an NHWC patch
+template <typename T>
+__global__ void __launch_bounds__(256)
+permute_patch_kernel(const float* __restrict__ w, int dim, int ch, int patch, typename T::elem* __restrict__ o) {
+    const int kp = patch * patch * ch;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)dim * kp) return;
+    const int d = (int)(i / kp), k = (int)(i - (int64_t)d * kp);
+    const int c = k % ch, kx = (k / ch) % patch, ky = k / (ch * patch);
+    o[i] = (typename T::elem)w[(((int64_t)d * ch + c) * patch + ky) * patch + kx];
+}
+hipError_t launch_permute_patch(const float* w, int dim, int channels, int patch, void* w16, int dtype, hipStream_t s) {
+    const int64_t n = (int64_t)dim * patch * patch * channels;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == VH_DTYPE_BF16) hipLaunchKernelGGL(permute_patch_kernel<BF16>, grid, block, 0, s, w, dim, channels, patch, (BF16::elem*)w16);
+    else hipLaunchKernelGGL(permute_patch_kernel<FP16>, grid, block, 0, s, w, dim, channels, patch, (FP16::elem*)w16);
+    return hipGetLastError();
+}
+
+// ---- MLP mode: one dense layer, fp32 exact products, one wave per output neuron ----------------------
+// y[v, j] = act(b[j] + sum_k W[j, k] x[v, k]) — the body of the reference's network_v1 layer loop
+// (argument layout netFPGA.cpp:427-436; weights row-major [n_out, n_in], netFPGA.cpp:94-105).
+__device__ __forceinline__ float act_apply(int act, float v) {
+    switch (act) {
+    case VH_ACT_RELU2: return fminf(fmaxf(v, 0.f), 1.f);
+    case VH_ACT_RELU: return fmaxf(v, 0.f);
+    case VH_ACT_HARDTANH: return fminf(fmaxf(v, -1.f), 1.f);
+    case VH_ACT_GELU: return gelu_erf(v);
+    default: return v;
+    }
+}
+__global__ void __launch_bounds__(256)
+dense_layer_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ x,
+                   float* __restrict__ y, int n_in, int n_out, int n_vec, int act) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n_out) return;
+    const float* wr = w + (int64_t)j * n_in;
+    for (int v = 0; v < n_vec; ++v) {
+        const float* xv = x + (int64_t)v * n_in;
+        float s = 0.f;
+        for (int k = lane; k < n_in; k += 64) s = fmaf(wr[k], xv[k], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) y[(int64_t)v * n_out + j] = act_apply(act, s + b[j]);
+    }
+}
+hipError_t launch_dense_layer(const float* w, const float* b, const float* x, float* y, int n_in, int n_out, int n_vec,
+                              int activation, hipStream_t s) {
+    hipLaunchKernelGGL(dense_layer_kernel, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, s, w, b, x, y, n_in, n_out,
+                       n_vec, activation);
+    return hipGetLastError();
+}
+
+hipError_t init_kernel_attributes() { return hipSuccess; }
+
+}  // namespace vh

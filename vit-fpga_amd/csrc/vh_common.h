@@ -1,0 +1,103 @@
+// vh_common.h — shared device/host helpers of libvithip (gfx950 / CDNA4 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vithip.h"
+
+namespace vh {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// 16-bit MFMA operand types.  All kernels are templated on one of these two.
+struct BF16 {
+    using elem = __bf16;
+    using vec8 = bf16x8;
+    using vec4 = bf16x4;
+    static constexpr int id = VH_DTYPE_BF16;
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ vec4 tr_read(const void* lds_addr) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (vec4 __attribute__((address_space(3)))*)(uintptr_t)lds_addr);
+    }
+};
+struct FP16 {
+    using elem = _Float16;
+    using vec8 = f16x8;
+    using vec4 = f16x4;
+    static constexpr int id = VH_DTYPE_FP16;
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ vec4 tr_read(const void* lds_addr) {
+        typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h4;
+        h4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (h4 __attribute__((address_space(3)))*)(uintptr_t)lds_addr);
+        return __builtin_bit_cast(vec4, r);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ typename T::vec4 pack4(float a, float b, float c, float d) {
+    typename T::vec4 v;
+    v[0] = (typename T::elem)a;
+    v[1] = (typename T::elem)b;
+    v[2] = (typename T::elem)c;
+    v[3] = (typename T::elem)d;
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) {
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+// ---- synthetic-data generator (DESIGN.md "synthetic data") -----------------------------
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+__host__ __device__ __forceinline__ uint64_t rng_stream(uint64_t seed, uint32_t tensor_id) {
+    return mix64(mix64(seed) ^ (uint64_t)tensor_id);
+}
+__host__ __device__ __forceinline__ float rng_uniform(uint64_t stream, uint64_t i) {
+    const uint64_t w = mix64(stream ^ i);
+    const int32_t u = (int32_t)(w >> 40) - (1 << 23);
+    return (float)u * (1.0f / 8388608.0f);
+}
+// offset + IrwinHall4 * sigma; `scale` = (double)sigma / 37837.22725
+__host__ __device__ __forceinline__ float rng_ih4(uint64_t stream, uint64_t i, double scale,
+                                                  float offset) {
+    const uint64_t w = mix64(stream ^ i);
+    const int32_t s = (int32_t)(w & 0xFFFF) + (int32_t)((w >> 16) & 0xFFFF) +
+                      (int32_t)((w >> 32) & 0xFFFF) + (int32_t)((w >> 48) & 0xFFFF) - 131070;
+    const float v = (float)((double)s * scale);
+    return offset + v;
+}
+constexpr double kIH4Std = 37837.22725;
+
+// tensor ids of the canonical blob (same numbers as oracle/ and tests/, by specification)
+enum : uint32_t { TID_PATCH_W = 1, TID_PATCH_B = 2, TID_CLS = 3, TID_POS = 4, TID_LAYER0 = 16,
+                  TID_FINAL = 0x7000, TID_IMAGES = 0x100 };
+
+}  // namespace vh

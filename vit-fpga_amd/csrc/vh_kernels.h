@@ -1,0 +1,52 @@
+// vh_kernels.h — internal launch API between the C-ABI layer (vithip_api.hip) and the kernels.
+#pragma once
+
+#include "vh_common.h"
+
+namespace vh {
+
+struct GemmArgs {
+    const void* a;      // [M, K] 16-bit, K contiguous
+    const void* w;      // [N, K] 16-bit, K contiguous
+    const float* bias;  // [N]
+    void* out;          // 16-bit or fp32 [M(or remapped rows), N]
+    int64_t M;
+    int N, K;
+    int epilogue;       // VH_EPI_*
+    const float* aux;   // EPI_PATCH: pos-emb [tokens, N]
+    int aux_i;          // EPI_PATCH: patches per image
+    int dtype;          // VH_DTYPE_*
+    int variant;        // 0 auto, 1 = 128x128, 2 = 256x256
+};
+
+// every launcher only enqueues on `stream`; returns hipSuccess or the launch error
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t stream);
+const char* gemm_check(const GemmArgs& g);  // NULL if the shape is supported, else the reason
+int gemm_pick_variant(int64_t M, int N);
+
+hipError_t launch_layernorm(const float* x, int64_t rows, int dim, int64_t row_stride,
+                            const float* gamma, const float* beta, float eps, void* out16,
+                            int dtype, hipStream_t stream);
+hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16,
+                            int dtype, hipStream_t stream);
+size_t attention_lds_bytes(int tokens);
+hipError_t launch_im2col(const float* in_nhwc, int batch, int image, int patch, int channels,
+                         void* out16, int dtype, hipStream_t stream);
+hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int batch, int tokens,
+                           int dim, hipStream_t stream);
+hipError_t launch_cast(const float* in, void* out16, int64_t n, int dtype, hipStream_t stream);
+hipError_t launch_fill(float* out, int64_t n, uint64_t seed, uint32_t tensor_id, int kind,
+                       float sigma, float offset, hipStream_t stream);
+// weight preparation (fp32 canonical tensors -> compute layout)
+hipError_t launch_pack_qkv(const float* qw, const float* qb, const float* kw, const float* kb,
+                           const float* vw, const float* vb, int dim, float q_scale, void* w16,
+                           float* b32, int dtype, hipStream_t stream);
+hipError_t launch_permute_patch(const float* w_nchw, int dim, int channels, int patch, void* w16,
+                                int dtype, hipStream_t stream);
+// MLP mode: y = act(W x + b), W [n_out, n_in] fp32
+hipError_t launch_dense_layer(const float* w, const float* b, const float* x, float* y, int n_in,
+                              int n_out, int n_vec, int activation, hipStream_t stream);
+
+hipError_t init_kernel_attributes();  // opt in to >64 KiB dynamic LDS, once per process
+
+}  // namespace vh

@@ -1,0 +1,746 @@
+// vithip_api.hip — the C ABI of libvithip.so (declared in include/vithip.h).
+//
+// Host-side runtime of the hot path: device/stream ownership, the HBM layout (canonical fp32
+// weight blob + 16-bit compute copies + one activation arena sized for max_batch), weight
+// preparation, and the launch sequence of one ViT forward.  Takes over the jobs of the
+// reference's _init_program/_init_kernel/_load_params/launch_forward/cleanup
+// (/root/reference/src/netFPGA.cpp:239-290, 367-515, 639-651) — see the per-function notes in
+// the header.  No CPU fallback exists: without a gfx950 device every compute entry point
+// fails with VH_ERR_NO_DEVICE / VH_ERR_HIP.
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vh_kernels.h"
+
+using namespace vh;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(std::string* ctx_err, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    if (ctx_err) *ctx_err = buf;
+    return code;
+}
+
+#define HIPCHK(ctxerr, expr)                                                                   \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctxerr, VH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+struct BlobHeader {
+    char magic[8];
+    int32_t image_size, patch_size, channels, dim, heads, mlp_dim, layers, classes;
+    float ln_eps;
+    uint32_t pad[5];
+};
+static_assert(sizeof(BlobHeader) == 64, "blob header is 64 bytes");
+
+struct LayerOff {  // offsets in floats from the start of the parameter region
+    size_t ln1w, ln1b, qw, qb, kw, kb, vw, vb, ow, ob, ln2w, ln2b, f1w, f1b, f2w, f2b;
+};
+
+struct Layout {
+    int T, NP, KP;
+    size_t patch_w, patch_b, cls, pos, lnfw, lnfb, headw, headb, total;
+    std::vector<LayerOff> layer;
+};
+
+Layout make_layout(const vh_config& c) {
+    Layout L;
+    const size_t D = c.dim, M = c.mlp_dim, C = c.classes;
+    const int g = c.image_size / c.patch_size;
+    L.NP = g * g;
+    L.T = L.NP + 1;
+    L.KP = c.patch_size * c.patch_size * c.channels;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += n; return r; };
+    L.patch_w = take(D * L.KP); L.patch_b = take(D); L.cls = take(D); L.pos = take((size_t)L.T * D);
+    L.layer.resize(c.layers);
+    for (int l = 0; l < c.layers; ++l) {
+        LayerOff& p = L.layer[l];
+        p.ln1w = take(D); p.ln1b = take(D);
+        p.qw = take(D * D); p.qb = take(D); p.kw = take(D * D); p.kb = take(D);
+        p.vw = take(D * D); p.vb = take(D); p.ow = take(D * D); p.ob = take(D);
+        p.ln2w = take(D); p.ln2b = take(D);
+        p.f1w = take(M * D); p.f1b = take(M); p.f2w = take(D * M); p.f2b = take(D);
+    }
+    L.lnfw = take(D); L.lnfb = take(D); L.headw = take(C * D); L.headb = take(C);
+    L.total = o;
+    return L;
+}
+
+const char* check_config(const vh_config& c) {
+    if (c.image_size <= 0 || c.patch_size <= 0 || c.image_size % c.patch_size) return "image_size must be a positive multiple of patch_size";
+    if (c.channels <= 0 || (c.patch_size * c.channels) % 4) return "patch_size*channels must be a multiple of 4";
+    if ((c.patch_size * c.patch_size * c.channels) % 64) return "patch_size^2*channels must be a multiple of 64";
+    if (c.dim <= 0 || c.dim % 64) return "dim must be a multiple of 64";
+    if (c.heads <= 0 || c.dim != c.heads * 64) return "dim/heads must be 64";
+    if (c.mlp_dim <= 0 || c.mlp_dim % 64) return "mlp_dim must be a multiple of 64";
+    if (c.dim > 2048) return "dim > 2048 unsupported";
+    if (c.layers <= 0) return "layers must be positive";
+    if (c.classes <= 0 || c.classes % 4) return "classes must be a positive multiple of 4";
+    if (c.dtype != VH_DTYPE_BF16 && c.dtype != VH_DTYPE_FP16) return "dtype must be VH_DTYPE_BF16 or VH_DTYPE_FP16";
+    if (c.max_batch <= 0) return "max_batch must be positive";
+    if (!(c.ln_eps > 0.f)) return "ln_eps must be positive";
+    if (c.reserved != 0) return "reserved must be 0";
+    const int g = c.image_size / c.patch_size;
+    if (attention_lds_bytes(g * g + 1) > 160 * 1024) return "token count too large for the LDS-resident attention kernel";
+    return nullptr;
+}
+
+enum Stage { ST_IM2COL, ST_PATCH, ST_CLS, ST_LN, ST_QKV, ST_ATTN, ST_PROJ, ST_FC1, ST_FC2, ST_LNF, ST_HEAD, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"im2col", "patch_gemm", "cls_rows", "layernorm", "qkv_gemm", "attention",
+                                     "proj_gemm", "fc1_gemm", "fc2_gemm", "final_layernorm", "head_gemm"};
+
+}  // namespace
+
+struct vh_ctx {
+    vh_config cfg;
+    int device;
+    Layout L;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool weights_ready = false;
+    int run_layers = -1;
+    // HBM: canonical blob (header + fp32 params) and the 16-bit compute copies
+    char* blob = nullptr;
+    float* params = nullptr;  // blob + 64
+    char* w16 = nullptr;      // arena of 16-bit matrices
+    void* wp16 = nullptr;     // [D, KP]
+    void* head16 = nullptr;   // [C, D]
+    std::vector<void*> wqkv16, wo16, w1_16, w2_16;
+    float* bqkv = nullptr;    // [layers, 3D]
+    // activations (sized for max_batch)
+    char* arena = nullptr;
+    float* x = nullptr;       // residual stream [B*T, D] fp32
+    void* xn16 = nullptr;     // LN output       [B*T, D]
+    void* qkv16 = nullptr;    //                 [B*T, 3D]
+    void* att16 = nullptr;    //                 [B*T, D]
+    void* h16 = nullptr;      //                 [B*T, M]
+    void* col16 = nullptr;    // patch matrix    [B*NP, KP]
+    void* clsn16 = nullptr;   // final-LN'd CLS  [B, D]
+    float* in_dev = nullptr;  // staging for the host-pointer forward
+    float* logits_dev = nullptr;
+    int64_t last_us = 0;
+    bool timed = false;
+    int last_batch = 0;
+    std::string err;
+};
+
+struct vh_mlp {
+    int device, n_ins, n_layers, activation;
+    std::vector<int> npl;
+    size_t n_params = 0, n_neurons = 0;
+    int widest = 0, max_vec = 0;
+    hipStream_t stream = nullptr;
+    float *params = nullptr, *bias = nullptr, *buf0 = nullptr, *buf1 = nullptr;
+    bool loaded = false;
+    int64_t last_us = 0;
+    std::string err;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int set_device(std::string* err, int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(err, VH_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(err, VH_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(err, hipSetDevice(device));
+    return VH_OK;
+}
+
+// convert the fp32 blob resident in ctx->blob into the compute layout
+int prepare_weights(vh_ctx* c) {
+    const vh_config& f = c->cfg;
+    const Layout& L = c->L;
+    const int D = f.dim, M = f.mlp_dim;
+    hipStream_t s = c->stream;
+    const float* P = c->params;
+    HIPCHK(&c->err, launch_permute_patch(P + L.patch_w, D, f.channels, f.patch_size, c->wp16, f.dtype, s));
+    for (int l = 0; l < f.layers; ++l) {
+        const LayerOff& o = L.layer[l];
+        HIPCHK(&c->err, launch_pack_qkv(P + o.qw, P + o.qb, P + o.kw, P + o.kb, P + o.vw, P + o.vb, D, 0.125f,
+                                        c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, f.dtype, s));
+        HIPCHK(&c->err, launch_cast(P + o.ow, c->wo16[l], (int64_t)D * D, f.dtype, s));
+        HIPCHK(&c->err, launch_cast(P + o.f1w, c->w1_16[l], (int64_t)M * D, f.dtype, s));
+        HIPCHK(&c->err, launch_cast(P + o.f2w, c->w2_16[l], (int64_t)D * M, f.dtype, s));
+    }
+    HIPCHK(&c->err, launch_cast(P + L.headw, c->head16, (int64_t)f.classes * D, f.dtype, s));
+    HIPCHK(&c->err, hipStreamSynchronize(s));
+    c->weights_ready = true;
+    return VH_OK;
+}
+
+int check_blob_header(vh_ctx* c, const BlobHeader& h) {
+    const vh_config& f = c->cfg;
+    if (memcmp(h.magic, "VHBLOB1", 8) != 0) return fail(&c->err, VH_ERR_INVALID, "weight blob: bad magic");
+    if (h.image_size != f.image_size || h.patch_size != f.patch_size || h.channels != f.channels || h.dim != f.dim ||
+        h.heads != f.heads || h.mlp_dim != f.mlp_dim || h.layers != f.layers || h.classes != f.classes)
+        return fail(&c->err, VH_ERR_INVALID, "weight blob: shape differs from the context's vh_config");
+    return VH_OK;
+}
+
+// the launch sequence of ONE forward; `ev` (optional) receives an event after every stage
+int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::vector<std::pair<int, hipEvent_t>>* ev) {
+    const vh_config& f = c->cfg;
+    const Layout& L = c->L;
+    const int D = f.dim, M = f.mlp_dim, T = L.T;
+    const int64_t rows = (int64_t)batch * T;
+    hipStream_t s = c->stream;
+    const float* P = c->params;
+    auto mark = [&](int stage) -> int {
+        if (!ev) return VH_OK;
+        hipEvent_t e;
+        HIPCHK(&c->err, hipEventCreate(&e));
+        HIPCHK(&c->err, hipEventRecord(e, s));
+        ev->push_back({stage, e});
+        return VH_OK;
+    };
+    auto gemm = [&](const void* a, const void* w, const float* bias, void* out, int64_t Mr, int N, int K, int epi,
+                    const float* aux, int aux_i) {
+        GemmArgs g{a, w, bias, out, Mr, N, K, epi, aux, aux_i, f.dtype, 0};
+        return launch_gemm(g, s);
+    };
+    int rc;
+    if ((rc = mark(-1))) return rc;
+    HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, c->col16, f.dtype, s));
+    if ((rc = mark(ST_IM2COL))) return rc;
+    HIPCHK(&c->err, gemm(c->col16, c->wp16, P + L.patch_b, c->x, (int64_t)batch * L.NP, D, L.KP, VH_EPI_PATCH, P + L.pos, L.NP));
+    if ((rc = mark(ST_PATCH))) return rc;
+    HIPCHK(&c->err, launch_cls_rows(c->x, P + L.cls, P + L.pos, batch, T, D, s));
+    if ((rc = mark(ST_CLS))) return rc;
+    const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
+    for (int l = 0; l < nl; ++l) {
+        const LayerOff& o = L.layer[l];
+        HIPCHK(&c->err, launch_layernorm(c->x, rows, D, D, P + o.ln1w, P + o.ln1b, f.ln_eps, c->xn16, f.dtype, s));
+        if ((rc = mark(ST_LN))) return rc;
+        HIPCHK(&c->err, gemm(c->xn16, c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, c->qkv16, rows, 3 * D, D, VH_EPI_BIAS, nullptr, 0));
+        if ((rc = mark(ST_QKV))) return rc;
+        HIPCHK(&c->err, launch_attention(c->qkv16, batch, T, f.heads, c->att16, f.dtype, s));
+        if ((rc = mark(ST_ATTN))) return rc;
+        HIPCHK(&c->err, gemm(c->att16, c->wo16[l], P + o.ob, c->x, rows, D, D, VH_EPI_BIAS_RESID, nullptr, 0));
+        if ((rc = mark(ST_PROJ))) return rc;
+        HIPCHK(&c->err, launch_layernorm(c->x, rows, D, D, P + o.ln2w, P + o.ln2b, f.ln_eps, c->xn16, f.dtype, s));
+        if ((rc = mark(ST_LN))) return rc;
+        HIPCHK(&c->err, gemm(c->xn16, c->w1_16[l], P + o.f1b, c->h16, rows, M, D, VH_EPI_BIAS_GELU, nullptr, 0));
+        if ((rc = mark(ST_FC1))) return rc;
+        HIPCHK(&c->err, gemm(c->h16, c->w2_16[l], P + o.f2b, c->x, rows, D, M, VH_EPI_BIAS_RESID, nullptr, 0));
+        if ((rc = mark(ST_FC2))) return rc;
+    }
+    HIPCHK(&c->err, launch_layernorm(c->x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, c->clsn16, f.dtype, s));
+    if ((rc = mark(ST_LNF))) return rc;
+    HIPCHK(&c->err, gemm(c->clsn16, c->head16, P + L.headb, logits, batch, f.classes, D, VH_EPI_BIAS_F32, nullptr, 0));
+    if ((rc = mark(ST_HEAD))) return rc;
+    c->last_batch = batch;
+    return VH_OK;
+}
+
+int check_forward_args(vh_ctx* c, const void* in, int batch, const void* out) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    if (!in || !out) return fail(&c->err, VH_ERR_INVALID, "null buffer");
+    if (batch <= 0 || batch > c->cfg.max_batch)
+        return fail(&c->err, VH_ERR_INVALID, "batch %d outside 1..max_batch=%d", batch, c->cfg.max_batch);
+    if (!c->weights_ready) return fail(&c->err, VH_ERR_STATE, "forward before weights were loaded");
+    return VH_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int vh_abi_version(void) { return VH_ABI_VERSION; }
+
+int vh_device_count(int* count) {
+    if (!count) return fail(nullptr, VH_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, VH_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return VH_OK;
+}
+
+const char* vh_last_error(const vh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int vh_malloc(int device, size_t nbytes, void** p) {
+    if (!p || !nbytes) return fail(nullptr, VH_ERR_INVALID, "vh_malloc: bad argument");
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    HIPCHK(nullptr, hipMalloc(p, nbytes));
+    return VH_OK;
+}
+int vh_free(int device, void* p) {
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    HIPCHK(nullptr, hipFree(p));
+    return VH_OK;
+}
+int vh_memcpy_h2d(int device, void* d, const void* h, size_t n) {
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    HIPCHK(nullptr, hipMemcpy(d, h, n, hipMemcpyHostToDevice));
+    return VH_OK;
+}
+int vh_memcpy_d2h(int device, void* h, const void* d, size_t n) {
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    HIPCHK(nullptr, hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+    return VH_OK;
+}
+int vh_device_synchronize(int device) {
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    HIPCHK(nullptr, hipDeviceSynchronize());
+    return VH_OK;
+}
+
+size_t vh_weight_blob_bytes(const vh_config* cfg) {
+    if (!cfg || check_config(*cfg)) return 0;
+    return sizeof(BlobHeader) + 4 * make_layout(*cfg).total;
+}
+
+int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, VH_ERR_INVALID, "vh_create: null argument");
+    *out = nullptr;
+    if (const char* why = check_config(*cfg)) return fail(nullptr, VH_ERR_INVALID, "vh_create: %s", why);
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, VH_ERR_NO_DEVICE, "device %d is %s; libvithip is built for gfx950 only", device, prop.gcnArchName);
+
+    vh_ctx* c = new vh_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    c->L = make_layout(*cfg);
+    const Layout& L = c->L;
+    const size_t D = cfg->dim, M = cfg->mlp_dim, C = cfg->classes, B = cfg->max_batch;
+    const size_t rows = B * (size_t)L.T;
+    auto bail = [&](int code) { vh_destroy(c); return code; };
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, VH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(VH_ERR_HIP); } } while (0)
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipEventCreate(&c->ev0));
+    CK(hipEventCreate(&c->ev1));
+    // canonical blob
+    CK(hipMalloc((void**)&c->blob, sizeof(BlobHeader) + 4 * L.total));
+    c->params = (float*)(c->blob + sizeof(BlobHeader));
+    // 16-bit weights
+    size_t w16_bytes = 0;
+    auto carve16 = [&](size_t elems) { size_t o = w16_bytes; w16_bytes += align_up(elems * 2, 256); return o; };
+    const size_t o_wp = carve16(D * L.KP), o_head = carve16(C * D);
+    std::vector<size_t> o_qkv(cfg->layers), o_o(cfg->layers), o_1(cfg->layers), o_2(cfg->layers);
+    for (int l = 0; l < cfg->layers; ++l) { o_qkv[l] = carve16(3 * D * D); o_o[l] = carve16(D * D); o_1[l] = carve16(M * D); o_2[l] = carve16(D * M); }
+    const size_t o_bqkv = w16_bytes;
+    w16_bytes += align_up((size_t)cfg->layers * 3 * D * 4, 256);
+    CK(hipMalloc((void**)&c->w16, w16_bytes));
+    c->wp16 = c->w16 + o_wp; c->head16 = c->w16 + o_head; c->bqkv = (float*)(c->w16 + o_bqkv);
+    for (int l = 0; l < cfg->layers; ++l) {
+        c->wqkv16.push_back(c->w16 + o_qkv[l]); c->wo16.push_back(c->w16 + o_o[l]);
+        c->w1_16.push_back(c->w16 + o_1[l]); c->w2_16.push_back(c->w16 + o_2[l]);
+    }
+    // activation arena
+    size_t a = 0;
+    auto carve = [&](size_t bytes) { size_t o = a; a += align_up(bytes, 256); return o; };
+    const size_t o_x = carve(rows * D * 4), o_xn = carve(rows * D * 2), o_qkvA = carve(rows * 3 * D * 2),
+                 o_att = carve(rows * D * 2), o_h = carve(rows * M * 2), o_col = carve(B * L.NP * (size_t)L.KP * 2),
+                 o_cls = carve(B * D * 2),
+                 o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4);
+    CK(hipMalloc((void**)&c->arena, a));
+    c->x = (float*)(c->arena + o_x); c->xn16 = c->arena + o_xn; c->qkv16 = c->arena + o_qkvA; c->att16 = c->arena + o_att;
+    c->h16 = c->arena + o_h; c->col16 = c->arena + o_col; c->clsn16 = c->arena + o_cls;
+    c->in_dev = (float*)(c->arena + o_in); c->logits_dev = (float*)(c->arena + o_lg);
+#undef CK
+    *out = c;
+    return VH_OK;
+}
+
+int vh_destroy(vh_ctx* c) {
+    if (!c) return VH_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->arena) hipFree(c->arena);
+    if (c->w16) hipFree(c->w16);
+    if (c->blob) hipFree(c->blob);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return VH_OK;
+}
+
+int vh_get_config(const vh_ctx* c, vh_config* out) {
+    if (!c || !out) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *out = c->cfg;
+    return VH_OK;
+}
+
+int vh_load_weights(vh_ctx* c, const void* host_blob, size_t nbytes) {
+    if (!c || !host_blob) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "vh_load_weights: null argument");
+    const size_t need = sizeof(BlobHeader) + 4 * c->L.total;
+    if (nbytes != need) return fail(&c->err, VH_ERR_INVALID, "weight blob is %zu bytes, expected %zu", nbytes, need);
+    BlobHeader h;
+    memcpy(&h, host_blob, sizeof h);
+    int rc = check_blob_header(c, h);
+    if (rc) return rc;
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    c->weights_ready = false;
+    HIPCHK(&c->err, hipMemcpyAsync(c->blob, host_blob, nbytes, hipMemcpyHostToDevice, c->stream));
+    return prepare_weights(c);
+}
+
+int vh_load_weights_device(vh_ctx* c, const void* dev_blob, size_t nbytes) {
+    if (!c || !dev_blob) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "vh_load_weights_device: null argument");
+    const size_t need = sizeof(BlobHeader) + 4 * c->L.total;
+    if (nbytes != need) return fail(&c->err, VH_ERR_INVALID, "weight blob is %zu bytes, expected %zu", nbytes, need);
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    BlobHeader h;
+    HIPCHK(&c->err, hipMemcpy(&h, dev_blob, sizeof h, hipMemcpyDeviceToHost));
+    int rc = check_blob_header(c, h);
+    if (rc) return rc;
+    c->weights_ready = false;
+    if (dev_blob != c->blob) HIPCHK(&c->err, hipMemcpyAsync(c->blob, dev_blob, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    return prepare_weights(c);
+}
+
+int vh_init_weights_seeded(vh_ctx* c, uint64_t seed) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    const vh_config& f = c->cfg;
+    const Layout& L = c->L;
+    BlobHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "VHBLOB1", 8);
+    h.image_size = f.image_size; h.patch_size = f.patch_size; h.channels = f.channels; h.dim = f.dim;
+    h.heads = f.heads; h.mlp_dim = f.mlp_dim; h.layers = f.layers; h.classes = f.classes; h.ln_eps = f.ln_eps;
+    c->weights_ready = false;
+    HIPCHK(&c->err, hipMemcpy(c->blob, &h, sizeof h, hipMemcpyHostToDevice));
+    const size_t D = f.dim, M = f.mlp_dim, C = f.classes;
+    const float sw = 0.02f, sb = 0.02f, sg = 0.05f;
+    float* P = c->params;
+    hipStream_t s = c->stream;
+#define GEN(off, count, tid, sigma, offs) HIPCHK(&c->err, launch_fill(P + (off), (int64_t)(count), seed, (tid), 1, (sigma), (offs), s))
+    GEN(L.patch_w, D * L.KP, TID_PATCH_W, sw, 0.f);
+    GEN(L.patch_b, D, TID_PATCH_B, sb, 0.f);
+    GEN(L.cls, D, TID_CLS, sw, 0.f);
+    GEN(L.pos, (size_t)L.T * D, TID_POS, sw, 0.f);
+    for (int l = 0; l < f.layers; ++l) {
+        const LayerOff& o = L.layer[l];
+        const uint32_t t = TID_LAYER0 + 16u * (uint32_t)l;
+        GEN(o.ln1w, D, t + 0, sg, 1.f); GEN(o.ln1b, D, t + 1, sb, 0.f);
+        GEN(o.qw, D * D, t + 2, sw, 0.f); GEN(o.qb, D, t + 3, sb, 0.f);
+        GEN(o.kw, D * D, t + 4, sw, 0.f); GEN(o.kb, D, t + 5, sb, 0.f);
+        GEN(o.vw, D * D, t + 6, sw, 0.f); GEN(o.vb, D, t + 7, sb, 0.f);
+        GEN(o.ow, D * D, t + 8, sw, 0.f); GEN(o.ob, D, t + 9, sb, 0.f);
+        GEN(o.ln2w, D, t + 10, sg, 1.f); GEN(o.ln2b, D, t + 11, sb, 0.f);
+        GEN(o.f1w, M * D, t + 12, sw, 0.f); GEN(o.f1b, M, t + 13, sb, 0.f);
+        GEN(o.f2w, D * M, t + 14, sw, 0.f); GEN(o.f2b, D, t + 15, sb, 0.f);
+    }
+    GEN(L.lnfw, D, TID_FINAL + 0, sg, 1.f); GEN(L.lnfb, D, TID_FINAL + 1, sb, 0.f);
+    GEN(L.headw, C * D, TID_FINAL + 2, sw, 0.f); GEN(L.headb, C, TID_FINAL + 3, sb, 0.f);
+#undef GEN
+    return prepare_weights(c);
+}
+
+int vh_export_weights(vh_ctx* c, void* host_blob, size_t nbytes) {
+    if (!c || !host_blob) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (!c->weights_ready) return fail(&c->err, VH_ERR_STATE, "no weights loaded");
+    const size_t need = sizeof(BlobHeader) + 4 * c->L.total;
+    if (nbytes != need) return fail(&c->err, VH_ERR_INVALID, "buffer is %zu bytes, blob is %zu", nbytes, need);
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipMemcpy(host_blob, c->blob, need, hipMemcpyDeviceToHost));
+    return VH_OK;
+}
+
+int vh_export_weights_device(vh_ctx* c, void* dev_blob, size_t nbytes) {
+    if (!c || !dev_blob) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (!c->weights_ready) return fail(&c->err, VH_ERR_STATE, "no weights loaded");
+    const size_t need = sizeof(BlobHeader) + 4 * c->L.total;
+    if (nbytes != need) return fail(&c->err, VH_ERR_INVALID, "buffer is %zu bytes, blob is %zu", nbytes, need);
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipMemcpy(dev_blob, c->blob, need, hipMemcpyDeviceToDevice));
+    return VH_OK;
+}
+
+int vh_forward_device_async(vh_ctx* c, const float* in, int batch, float* logits, int steps) {
+    int rc = check_forward_args(c, in, batch, logits);
+    if (rc) return rc;
+    if (steps <= 0) return fail(&c->err, VH_ERR_INVALID, "steps must be positive");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < steps; ++i)
+        if ((rc = enqueue_forward(c, in, batch, logits, nullptr))) return rc;
+    HIPCHK(&c->err, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return VH_OK;
+}
+
+int vh_synchronize(vh_ctx* c) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    return VH_OK;
+}
+
+int vh_forward_device(vh_ctx* c, const float* in, int batch, float* logits) {
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    int rc = vh_forward_device_async(c, in, batch, logits, 1);
+    if (rc) return rc;
+    rc = vh_synchronize(c);
+    if (rc) return rc;
+    c->last_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    return VH_OK;
+}
+
+int vh_forward(vh_ctx* c, const float* in_host, int batch, float* logits_host) {
+    int rc = check_forward_args(c, in_host, batch, logits_host);
+    if (rc) return rc;
+    const vh_config& f = c->cfg;
+    // same timing window as the reference: H2D + device work + blocking D2H (netFPGA.cpp:262-284)
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)batch * f.image_size * f.image_size * f.channels * 4;
+    HIPCHK(&c->err, hipMemcpyAsync(c->in_dev, in_host, in_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = vh_forward_device_async(c, c->in_dev, batch, c->logits_dev, 1);
+    if (rc) return rc;
+    HIPCHK(&c->err, hipMemcpyAsync(logits_host, c->logits_dev, (size_t)batch * f.classes * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    c->last_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    return VH_OK;
+}
+
+int vh_fill_input_seeded(vh_ctx* c, uint64_t seed, int batch, float* in_dev) {
+    if (!c || !in_dev || batch <= 0) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "bad argument");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    const int64_t n = (int64_t)batch * c->cfg.image_size * c->cfg.image_size * c->cfg.channels;
+    HIPCHK(&c->err, launch_fill(in_dev, n, seed, TID_IMAGES, 0, 0.f, 0.f, c->stream));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    return VH_OK;
+}
+
+int vh_last_forward_us(const vh_ctx* c, int64_t* us) {
+    if (!c || !us) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *us = c->last_us;
+    return VH_OK;
+}
+
+int vh_last_kernel_ms(vh_ctx* c, double* ms) {
+    if (!c || !ms) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    if (!c->timed) return fail(&c->err, VH_ERR_STATE, "no forward has been enqueued yet");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipEventSynchronize(c->ev1));
+    float t = 0.f;
+    HIPCHK(&c->err, hipEventElapsedTime(&t, c->ev0, c->ev1));
+    *ms = t;
+    return VH_OK;
+}
+
+const char* vh_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+
+int vh_profile_forward(vh_ctx* c, const float* in, int batch, float* logits, double* stage_ms, int n_slots, int* n_written) {
+    int rc = check_forward_args(c, in, batch, logits);
+    if (rc) return rc;
+    if (!stage_ms || n_slots < 2 * ST_COUNT) return fail(&c->err, VH_ERR_INVALID, "need %d stage slots (ms then launch counts)", 2 * ST_COUNT);
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    std::vector<std::pair<int, hipEvent_t>> ev;
+    rc = enqueue_forward(c, in, batch, logits, &ev);
+    if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) rc = fail(&c->err, VH_ERR_HIP, "sync: %s", hipGetErrorString(e)); }
+    for (int i = 0; i < 2 * ST_COUNT; ++i) stage_ms[i] = 0.0;
+    if (!rc)
+        for (size_t i = 1; i < ev.size(); ++i) {
+            float t = 0.f;
+            hipEventElapsedTime(&t, ev[i - 1].second, ev[i].second);
+            stage_ms[ev[i].first] += t;
+            stage_ms[ST_COUNT + ev[i].first] += 1.0;
+        }
+    for (auto& p : ev) hipEventDestroy(p.second);
+    if (n_written) *n_written = ST_COUNT;
+    return rc;
+}
+
+int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
+    if (!c || !host_out) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (c->last_batch <= 0) return fail(&c->err, VH_ERR_STATE, "no forward has run");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    const size_t D = c->cfg.dim;
+    if (what == 0) {
+        const size_t n = (size_t)c->last_batch * c->L.T * D;
+        if (n_floats != n) return fail(&c->err, VH_ERR_INVALID, "expected %zu floats", n);
+        HIPCHK(&c->err, hipMemcpy(host_out, c->x, n * 4, hipMemcpyDeviceToHost));
+        return VH_OK;
+    }
+    if (what == 1) {
+        const size_t n = (size_t)c->last_batch * D;
+        if (n_floats != n) return fail(&c->err, VH_ERR_INVALID, "expected %zu floats", n);
+        std::vector<uint16_t> tmp(n);
+        HIPCHK(&c->err, hipMemcpy(tmp.data(), c->clsn16, n * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            if (c->cfg.dtype == VH_DTYPE_BF16) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&host_out[i], &u, 4); }
+            else { _Float16 hval; memcpy(&hval, &tmp[i], 2); host_out[i] = (float)hval; }
+        }
+        return VH_OK;
+    }
+    return fail(&c->err, VH_ERR_INVALID, "unknown tap %d", what);
+}
+
+int vh_debug_set_layers(vh_ctx* c, int n_layers) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    c->run_layers = n_layers;
+    return VH_OK;
+}
+
+// ---- operator-level entry points ------------------------------------------------------------------
+#define OPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(nullptr, VH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+int vh_op_gemm(const void* a, const void* w, const float* bias, void* out, int64_t M, int N, int K, int epi,
+               const float* aux, int aux_i, int dtype, int variant, void* stream) {
+    GemmArgs g{a, w, bias, out, M, N, K, epi, aux, aux_i, dtype, variant};
+    if (const char* why = gemm_check(g)) return fail(nullptr, VH_ERR_INVALID, "%s", why);
+    OPCHK(launch_gemm(g, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_layernorm(const float* x, int64_t rows, int dim, int64_t row_stride, const float* gamma, const float* beta,
+                    float eps, void* out16, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !out16) return fail(nullptr, VH_ERR_INVALID, "null pointer");
+    if (dim <= 0 || dim % 4 || dim > 2048 || rows <= 0 || row_stride % 4) return fail(nullptr, VH_ERR_INVALID, "layernorm: unsupported shape");
+    OPCHK(launch_layernorm(x, rows, dim, row_stride, gamma, beta, eps, out16, dtype, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_attention(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype, void* stream) {
+    if (!qkv16 || !out16) return fail(nullptr, VH_ERR_INVALID, "null pointer");
+    if (batch <= 0 || tokens <= 0 || heads <= 0 || attention_lds_bytes(tokens) > 160 * 1024)
+        return fail(nullptr, VH_ERR_INVALID, "attention: unsupported shape");
+    OPCHK(launch_attention(qkv16, batch, tokens, heads, out16, dtype, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_im2col(const float* in, int batch, int image, int patch, int channels, void* out16, int dtype, void* stream) {
+    if (!in || !out16) return fail(nullptr, VH_ERR_INVALID, "null pointer");
+    if (batch <= 0 || patch <= 0 || image <= 0 || image % patch || (patch * channels) % 4)
+        return fail(nullptr, VH_ERR_INVALID, "im2col: unsupported shape");
+    OPCHK(launch_im2col(in, batch, image, patch, channels, out16, dtype, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_cast(const float* in, void* out16, int64_t n, int dtype, void* stream) {
+    if (!in || !out16 || n <= 0 || n % 4) return fail(nullptr, VH_ERR_INVALID, "cast: bad argument");
+    OPCHK(launch_cast(in, out16, n, dtype, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_fill(float* out, int64_t n, uint64_t seed, uint32_t tensor_id, int kind, float sigma, void* stream) {
+    if (!out || n <= 0 || kind < 0 || kind > 2) return fail(nullptr, VH_ERR_INVALID, "fill: bad argument");
+    OPCHK(launch_fill(out, n, seed, tensor_id, kind, kind == 2 ? 0.f : sigma, kind == 2 ? sigma : 0.f, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+
+// ---- MLP mode ------------------------------------------------------------------------------------
+int vh_mlp_create(int device, int n_ins, int n_layers, const int* n_p_l, int activation, vh_mlp** out) {
+    if (!out || !n_p_l || n_ins <= 0 || n_layers <= 0) return fail(nullptr, VH_ERR_INVALID, "vh_mlp_create: bad argument");
+    if (activation < VH_ACT_IDENTITY || activation > VH_ACT_GELU) return fail(nullptr, VH_ERR_INVALID, "unknown activation %d", activation);
+    *out = nullptr;
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    vh_mlp* m = new vh_mlp();
+    m->device = device; m->n_ins = n_ins; m->n_layers = n_layers; m->activation = activation;
+    m->widest = n_ins;
+    int fan = n_ins;
+    for (int l = 0; l < n_layers; ++l) {
+        if (n_p_l[l] <= 0) { delete m; return fail(nullptr, VH_ERR_INVALID, "n_p_l[%d] must be positive", l); }
+        m->npl.push_back(n_p_l[l]);
+        m->n_params += (size_t)n_p_l[l] * fan;   // netFPGA.cpp:68-76
+        m->n_neurons += (size_t)n_p_l[l];
+        fan = n_p_l[l];
+        if (fan > m->widest) m->widest = fan;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->params, m->n_params * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->bias, m->n_neurons * 4);
+    if (e != hipSuccess) { vh_mlp_destroy(m); return fail(nullptr, VH_ERR_HIP, "vh_mlp_create: %s", hipGetErrorString(e)); }
+    *out = m;
+    return VH_OK;
+}
+
+int vh_mlp_load_params(vh_mlp* m, const float* params, size_t n_params, const float* bias, size_t n_neurons) {
+    if (!m || !params || !bias) return fail(m ? &m->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (n_params != m->n_params || n_neurons != m->n_neurons)
+        return fail(&m->err, VH_ERR_INVALID, "expected %zu params / %zu neurons, got %zu / %zu", m->n_params, m->n_neurons, n_params, n_neurons);
+    HIPCHK(&m->err, hipSetDevice(m->device));
+    // same order as the reference: params, then bias (netFPGA.cpp:506-509)
+    HIPCHK(&m->err, hipMemcpyAsync(m->params, params, n_params * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(&m->err, hipMemcpyAsync(m->bias, bias, n_neurons * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(&m->err, hipStreamSynchronize(m->stream));
+    m->loaded = true;
+    return VH_OK;
+}
+
+int vh_mlp_forward(vh_mlp* m, const float* in, int n_vec, float* outp) {
+    if (!m || !in || !outp || n_vec <= 0) return fail(m ? &m->err : nullptr, VH_ERR_INVALID, "bad argument");
+    if (!m->loaded) return fail(&m->err, VH_ERR_STATE, "forward before params were loaded");
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    HIPCHK(&m->err, hipSetDevice(m->device));
+    if (n_vec > m->max_vec) {
+        if (m->buf0) hipFree(m->buf0);
+        if (m->buf1) hipFree(m->buf1);
+        m->buf0 = m->buf1 = nullptr; m->max_vec = 0;
+        HIPCHK(&m->err, hipMalloc((void**)&m->buf0, (size_t)n_vec * m->widest * 4));
+        HIPCHK(&m->err, hipMalloc((void**)&m->buf1, (size_t)n_vec * m->widest * 4));
+        m->max_vec = n_vec;
+    }
+    HIPCHK(&m->err, hipMemcpyAsync(m->buf0, in, (size_t)n_vec * m->n_ins * 4, hipMemcpyHostToDevice, m->stream));
+    float *cur = m->buf0, *nxt = m->buf1;
+    size_t woff = 0, boff = 0;
+    int fan = m->n_ins;
+    for (int l = 0; l < m->n_layers; ++l) {
+        HIPCHK(&m->err, launch_dense_layer(m->params + woff, m->bias + boff, cur, nxt, fan, m->npl[l], n_vec, m->activation, m->stream));
+        woff += (size_t)m->npl[l] * fan; boff += (size_t)m->npl[l]; fan = m->npl[l];
+        std::swap(cur, nxt);
+    }
+    HIPCHK(&m->err, hipMemcpyAsync(outp, cur, (size_t)n_vec * fan * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(&m->err, hipStreamSynchronize(m->stream));
+    m->last_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    return VH_OK;
+}
+
+int vh_mlp_last_forward_us(const vh_mlp* m, int64_t* us) {
+    if (!m || !us) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *us = m->last_us;
+    return VH_OK;
+}
+const char* vh_mlp_last_error(const vh_mlp* m) { return m ? m->err.c_str() : g_err.c_str(); }
+
+int vh_mlp_destroy(vh_mlp* m) {
+    if (!m) return VH_OK;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    if (m->params) hipFree(m->params);
+    if (m->bias) hipFree(m->bias);
+    if (m->buf0) hipFree(m->buf0);
+    if (m->buf1) hipFree(m->buf1);
+    if (m->stream) hipStreamDestroy(m->stream);
+    delete m;
+    return VH_OK;
+}
+
+}  // extern "C"

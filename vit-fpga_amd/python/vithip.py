@@ -1,0 +1,322 @@
+"""ctypes binding of libvithip.so — the thin host-side mirror used by tests/, bench.py and
+__graft_entry__.py.  Everything goes through the C ABI declared in include/vithip.h; there is
+no Python compute path and no fallback: if the library is missing, import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+LIB_PATH = os.path.join(PKG_ROOT, "libvithip.so")
+
+DTYPE_BF16, DTYPE_FP16 = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH = range(5)
+ACT_IDENTITY, ACT_RELU2, ACT_RELU, ACT_HARDTANH, ACT_GELU = range(5)
+
+STAGES = ["im2col", "patch_gemm", "cls_rows", "layernorm", "qkv_gemm", "attention", "proj_gemm",
+          "fc1_gemm", "fc2_gemm", "final_layernorm", "head_gemm"]
+
+
+class VhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvithip error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("image_size", C.c_int32), ("patch_size", C.c_int32), ("channels", C.c_int32),
+                ("dim", C.c_int32), ("heads", C.c_int32), ("mlp_dim", C.c_int32),
+                ("layers", C.c_int32), ("classes", C.c_int32), ("dtype", C.c_int32),
+                ("max_batch", C.c_int32), ("ln_eps", C.c_float), ("reserved", C.c_int32)]
+
+
+# every exported symbol of include/vithip.h: name -> (restype, argtypes)
+_vp, _i, _i64, _u64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_size_t, C.c_float
+_pi = C.POINTER(C.c_int)
+SYMBOLS = {
+    "vh_abi_version": (_i, []),
+    "vh_device_count": (_i, [_pi]),
+    "vh_last_error": (C.c_char_p, [_vp]),
+    "vh_malloc": (_i, [_i, _sz, C.POINTER(_vp)]),
+    "vh_free": (_i, [_i, _vp]),
+    "vh_memcpy_h2d": (_i, [_i, _vp, _vp, _sz]),
+    "vh_memcpy_d2h": (_i, [_i, _vp, _vp, _sz]),
+    "vh_device_synchronize": (_i, [_i]),
+    "vh_create": (_i, [C.POINTER(Config), _i, C.POINTER(_vp)]),
+    "vh_destroy": (_i, [_vp]),
+    "vh_get_config": (_i, [_vp, C.POINTER(Config)]),
+    "vh_weight_blob_bytes": (_sz, [C.POINTER(Config)]),
+    "vh_load_weights": (_i, [_vp, _vp, _sz]),
+    "vh_load_weights_device": (_i, [_vp, _vp, _sz]),
+    "vh_init_weights_seeded": (_i, [_vp, _u64]),
+    "vh_export_weights": (_i, [_vp, _vp, _sz]),
+    "vh_export_weights_device": (_i, [_vp, _vp, _sz]),
+    "vh_forward": (_i, [_vp, _vp, _i, _vp]),
+    "vh_forward_device": (_i, [_vp, _vp, _i, _vp]),
+    "vh_forward_device_async": (_i, [_vp, _vp, _i, _vp, _i]),
+    "vh_synchronize": (_i, [_vp]),
+    "vh_fill_input_seeded": (_i, [_vp, _u64, _i, _vp]),
+    "vh_last_forward_us": (_i, [_vp, C.POINTER(_i64)]),
+    "vh_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double)]),
+    "vh_profile_forward": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_double), _i, _pi]),
+    "vh_stage_name": (C.c_char_p, [_i]),
+    "vh_debug_read": (_i, [_vp, _i, _vp, _sz]),
+    "vh_debug_set_layers": (_i, [_vp, _i]),
+    "vh_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "vh_op_layernorm": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _f, _vp, _i, _vp]),
+    "vh_op_attention": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "vh_op_im2col": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "vh_op_cast": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "vh_op_fill": (_i, [_vp, _i64, _u64, C.c_uint32, _i, _f, _vp]),
+    "vh_mlp_create": (_i, [_i, _i, _i, _pi, _i, C.POINTER(_vp)]),
+    "vh_mlp_load_params": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "vh_mlp_forward": (_i, [_vp, _vp, _i, _vp]),
+    "vh_mlp_last_forward_us": (_i, [_vp, C.POINTER(_i64)]),
+    "vh_mlp_last_error": (C.c_char_p, [_vp]),
+    "vh_mlp_destroy": (_i, [_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libvithip.so (in-tree build).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: run `make -C vit-fpga_amd` (or "
+                              "__graft_entry__.build()); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().vh_last_error(ctx)
+        raise VhError(rc, msg.decode() if msg else "?")
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().vh_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def make_config(cfg, dtype=DTYPE_BF16, max_batch=1, ln_eps=1e-6):
+    return Config(cfg["image_size"], cfg["patch_size"], cfg["channels"], cfg["dim"], cfg["heads"],
+                  cfg["mlp_dim"], cfg["layers"], cfg["classes"], dtype, max_batch, ln_eps, 0)
+
+
+# ---- 16-bit helpers (host side, for building operator inputs / reading operator outputs) -------
+def to_bf16_bits(a):
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))
+    return (r >> np.uint32(16)).astype(np.uint16)
+
+
+def from_bf16_bits(b):
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def to16(a, dtype):
+    return to_bf16_bits(a) if dtype == DTYPE_BF16 else np.ascontiguousarray(a, dtype=np.float16).view(np.uint16)
+
+
+def from16(b, dtype):
+    return from_bf16_bits(b) if dtype == DTYPE_BF16 else np.ascontiguousarray(b, dtype=np.uint16).view(np.float16).astype(np.float32)
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned through vh_malloc/vh_free."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = device, int(nbytes)
+        p = C.c_void_p()
+        _check(lib().vh_malloc(device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a, device=0):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes, device)
+        _check(lib().vh_memcpy_h2d(device, b.ptr, a.ctypes.data, a.nbytes))
+        return b
+
+    def to_numpy(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _check(lib().vh_memcpy_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().vh_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class VitContext:
+    """vh_ctx wrapper: create / load weights / forward, mirroring hip::net_hip's ViT mode."""
+
+    def __init__(self, cfg, dtype=DTYPE_BF16, max_batch=1, device=0, ln_eps=1e-6):
+        self.cfg, self.dtype, self.device = dict(cfg), dtype, device
+        self.c = make_config(cfg, dtype, max_batch, ln_eps)
+        h = C.c_void_p()
+        _check(lib().vh_create(C.byref(self.c), device, C.byref(h)))
+        self.h = h.value
+
+    def close(self):
+        if self.h:
+            lib().vh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def blob_bytes(self):
+        return lib().vh_weight_blob_bytes(C.byref(self.c))
+
+    def load_weights(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        _check(lib().vh_load_weights(self.h, blob.ctypes.data, blob.nbytes), self.h)
+
+    def load_weights_device(self, ptr, nbytes):
+        _check(lib().vh_load_weights_device(self.h, ptr, nbytes), self.h)
+
+    def init_weights_seeded(self, seed):
+        _check(lib().vh_init_weights_seeded(self.h, seed), self.h)
+
+    def export_weights(self):
+        out = np.empty(self.blob_bytes, dtype=np.uint8)
+        _check(lib().vh_export_weights(self.h, out.ctypes.data, out.nbytes), self.h)
+        return out
+
+    def export_weights_device(self, ptr, nbytes):
+        _check(lib().vh_export_weights_device(self.h, ptr, nbytes), self.h)
+
+    def forward(self, images):
+        """images: [B, H, W, C] fp32 (host).  Returns [B, classes] fp32 logits."""
+        images = np.ascontiguousarray(images, dtype=np.float32)
+        b = images.shape[0]
+        out = np.empty((b, self.cfg["classes"]), dtype=np.float32)
+        _check(lib().vh_forward(self.h, images.ctypes.data, b, out.ctypes.data), self.h)
+        return out
+
+    def forward_device(self, in_ptr, batch, out_ptr):
+        _check(lib().vh_forward_device(self.h, in_ptr, batch, out_ptr), self.h)
+
+    def forward_device_async(self, in_ptr, batch, out_ptr, steps=1):
+        _check(lib().vh_forward_device_async(self.h, in_ptr, batch, out_ptr, steps), self.h)
+
+    def synchronize(self):
+        _check(lib().vh_synchronize(self.h), self.h)
+
+    def fill_input_seeded(self, seed, batch, in_ptr):
+        _check(lib().vh_fill_input_seeded(self.h, seed, batch, in_ptr), self.h)
+
+    def last_forward_us(self):
+        v = C.c_int64(0)
+        _check(lib().vh_last_forward_us(self.h, C.byref(v)), self.h)
+        return v.value
+
+    def last_kernel_ms(self):
+        v = C.c_double(0)
+        _check(lib().vh_last_kernel_ms(self.h, C.byref(v)), self.h)
+        return v.value
+
+    def profile_forward(self, in_ptr, batch, out_ptr):
+        n = len(STAGES)
+        arr = (C.c_double * (2 * n))()
+        nw = C.c_int(0)
+        _check(lib().vh_profile_forward(self.h, in_ptr, batch, out_ptr, arr, 2 * n, C.byref(nw)), self.h)
+        return {STAGES[i]: (arr[i], int(arr[n + i])) for i in range(n)}
+
+    def debug_read(self, what, n_floats):
+        out = np.empty(n_floats, dtype=np.float32)
+        _check(lib().vh_debug_read(self.h, what, out.ctypes.data, n_floats), self.h)
+        return out
+
+    def debug_set_layers(self, n):
+        _check(lib().vh_debug_set_layers(self.h, n), self.h)
+
+
+class MlpContext:
+    """vh_mlp wrapper — the reference's real launch_forward semantics (dense-layer chain)."""
+
+    def __init__(self, n_ins, n_p_l, activation=ACT_RELU2, device=0):
+        self.n_ins, self.n_p_l = n_ins, list(n_p_l)
+        arr = (C.c_int * len(n_p_l))(*n_p_l)
+        h = C.c_void_p()
+        _check(lib().vh_mlp_create(device, n_ins, len(n_p_l), arr, activation, C.byref(h)))
+        self.h = h.value
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = lib().vh_mlp_last_error(self.h)
+            raise VhError(rc, msg.decode() if msg else "?")
+
+    def load_params(self, params, bias):
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        b = np.ascontiguousarray(bias, dtype=np.float32)
+        self._chk(lib().vh_mlp_load_params(self.h, p.ctypes.data, p.size, b.ctypes.data, b.size))
+
+    def forward(self, inputs):
+        x = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, self.n_ins)
+        out = np.empty((x.shape[0], self.n_p_l[-1]), dtype=np.float32)
+        self._chk(lib().vh_mlp_forward(self.h, x.ctypes.data, x.shape[0], out.ctypes.data))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().vh_mlp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- operator-level wrappers (device pointers in, nothing hidden) ------------------------------------
+def op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, dtype, aux_ptr=None, aux_i=0, variant=0):
+    _check(lib().vh_op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, aux_ptr, aux_i, dtype, variant, None))
+
+
+def op_layernorm(x_ptr, rows, dim, row_stride, gamma_ptr, beta_ptr, eps, out_ptr, dtype):
+    _check(lib().vh_op_layernorm(x_ptr, rows, dim, row_stride, gamma_ptr, beta_ptr, eps, out_ptr, dtype, None))
+
+
+def op_attention(qkv_ptr, batch, tokens, heads, out_ptr, dtype):
+    _check(lib().vh_op_attention(qkv_ptr, batch, tokens, heads, out_ptr, dtype, None))
+
+
+def op_im2col(in_ptr, batch, image, patch, channels, out_ptr, dtype):
+    _check(lib().vh_op_im2col(in_ptr, batch, image, patch, channels, out_ptr, dtype, None))
+
+
+def op_cast(in_ptr, out_ptr, n, dtype):
+    _check(lib().vh_op_cast(in_ptr, out_ptr, n, dtype, None))
+
+
+def op_fill(out_ptr, n, seed, tensor_id, kind, sigma=0.0):
+    _check(lib().vh_op_fill(out_ptr, n, seed, tensor_id, kind, sigma, None))
