@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the ViT hot path on N MI355X (one process per GPU).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward of libvithip.so over one batch of synthetic images that is already
+resident in HBM (ViT-B/16, 224x224x3, 512 images per GPU, bf16 MFMA operands / fp32 accumulate).
+Images are sharded across ranks (independent units, no data-path collective): rank 0 generates the
+weights, the canonical blob is RCCL-broadcast over xGMI once, every rank then runs its own forward.
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job images/s, plus
+  roofline     — the dominant kernel (fc1 GEMM, 256x256-tile MFMA kernel with the GELU epilogue):
+                 algorithmic FLOP per launch / average launch duration, measured with hip events on
+                 the context's stream inside the timed region, against the dense bf16 MFMA peak;
+  cpu_baseline — the CPU oracle (oracle/liboracle.so, a port: the reference has no CPU path) timed
+                 on the host cores on a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vit-fpga_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0}  # dense MFMA peak, MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU")
+    ap.add_argument("--config", default="vit_base")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even with one rank")
+    ap.add_argument("--stages", action="store_true", help="also print a per-stage time table to stderr")
+    args = ap.parse_args()
+
+    import vh_dist
+    rank, world, local_rank = vh_dist.env_ranks()
+    use_dist = world > 1 or args.force_dist
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
+
+    torch = dist = None
+    if use_dist:
+        # torch first: its bundled HIP runtime is then the one libvithip.so binds to as well
+        torch, dist = vh_dist.init_process_group("nccl", rank, world, local_rank)
+
+    import numpy as np
+    import vh_synth as S
+    import vithip
+
+    cfg = S.CONFIGS[args.config]
+    dt = vithip.DTYPE_BF16 if args.dtype == "bf16" else vithip.DTYPE_FP16
+    B = args.batch
+    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B, device=local_rank)
+
+    # ---- weights: rank 0 generates, RCCL broadcast of the canonical fp32 blob ---------------------
+    if use_dist:
+        nbytes = ctx.blob_bytes
+        wbuf = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            ctx.init_weights_seeded(0)
+            ctx.export_weights_device(wbuf.data_ptr(), nbytes)
+        torch.cuda.synchronize()
+        vh_dist.broadcast_blob(dist, wbuf, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            ctx.load_weights_device(wbuf.data_ptr(), nbytes)
+        del wbuf
+    else:
+        ctx.init_weights_seeded(0)
+
+    # ---- synthetic batch, generated in HBM (each rank its own shard of the global batch) ----------
+    img_floats = B * cfg["image_size"] ** 2 * cfg["channels"]
+    din = vithip.DeviceBuffer(img_floats * 4, device=local_rank)
+    dout = vithip.DeviceBuffer(B * cfg["classes"] * 4, device=local_rank)
+    ctx.fill_input_seeded(1 + rank, B, din.ptr)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    def sync():
+        ctx.synchronize()
+        if use_dist:
+            torch.cuda.synchronize()
+
+    # ---- warm-up ---------------------------------------------------------------------------------
+    if args.warmup > 0:
+        ctx.forward_device_async(din.ptr, B, dout.ptr, steps=args.warmup)
+    sync()
+
+    # ---- timed region: exactly K steps ----------------------------------------------------------------
+    ctx.set_stage_timing("fc1_gemm")
+    barrier(); sync()
+    t0 = time.perf_counter()
+    ctx.forward_device_async(din.ptr, B, dout.ptr, steps=args.steps)
+    sync(); barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    fc1_avg_ms, fc1_min_ms, fc1_n = ctx.get_stage_timing()
+    ctx.set_stage_timing(None)
+    if use_dist:
+        elapsed = vh_dist.max_over_ranks(torch, dist, elapsed, f"cuda:{local_rank}")
+
+    logits = dout.to_numpy(np.float32, (B, cfg["classes"]))
+    if not np.isfinite(logits).all():
+        raise SystemExit("non-finite logits")
+
+    stages = None
+    if args.stages and rank == 0:
+        stages = ctx.profile_forward(din.ptr, B, dout.ptr)
+
+    if rank == 0:
+        total_images = B * world * args.steps
+        ips = total_images / elapsed
+        flops_img = S.flops_per_image(cfg)
+        T = S.tokens(cfg)
+        fc1_flops = 2.0 * B * T * cfg["mlp_dim"] * cfg["dim"]
+        achieved = fc1_flops / (fc1_avg_ms * 1e-3) / 1e12 if fc1_avg_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[args.dtype]
+        out = {
+            "metric": "images/sec ViT-B/16 224x224, batch 512 per GPU" if args.config == "vit_base" and B == 512
+                      else f"images/sec {args.config} batch {B} per GPU",
+            "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.config} {cfg['image_size']}x{cfg['image_size']}x{cfg['channels']} inference, "
+                                   f"{B} images per GPU resident in HBM, random-init weights (seed 0)",
+                       "global_batch": B * world, "per_gpu_batch": B,
+                       "parallelism": f"image-sharded x{world}, weights RCCL-broadcast once, no data-path collective",
+                       "flop_per_image": flops_img},
+            "forward_mfma_frac": round(ips / world * flops_img / (peak * 1e12), 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<256x256x64, bias+GELU> (fc1)",
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "flop_per_launch": fc1_flops, "avg_launch_ms": round(fc1_avg_ms, 5),
+                         "min_launch_ms": round(fc1_min_ms, 5), "launches_timed": fc1_n},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        if stages:
+            tot = sum(v[0] for v in stages.values())
+            for k, (ms, n) in stages.items():
+                print(f"  {k:16s} {ms:9.3f} ms  {n:3d} launches  {100 * ms / tot:5.1f} %", file=sys.stderr)
+            print(f"  {'total':16s} {tot:9.3f} ms", file=sys.stderr)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, target_seconds):
+    """The CPU oracle (a port — the reference ships no CPU path) on a bounded sample of the workload."""
+    import oracle_lib as O
+    import vh_synth as S
+    # the GPU box grants a CPU share of 16 cores per GPU even though more are visible
+    cores = min(16, len(os.sched_getaffinity(0)))
+    blob = S.make_blob(cfg, 0)
+    probe = S.make_images(cfg, 1, 2)
+    O.vit_forward(cfg, blob, probe[:1], threads=cores)  # touch pages / spin up the thread pool
+    t = time.perf_counter()
+    O.vit_forward(cfg, blob, probe, threads=cores)
+    per_img = (time.perf_counter() - t) / 2
+    n = int(max(2, min(64, target_seconds / max(per_img, 1e-6))))
+    imgs = S.make_images(cfg, 1, n)
+    t = time.perf_counter()
+    O.vit_forward(cfg, blob, imgs, threads=cores)
+    dtm = time.perf_counter() - t
+    return {"value": round(n / dtm, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} images of the same workload through oracle/liboracle.so (fp32, OpenMP, {cores} threads), "
+                      f"{dtm:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

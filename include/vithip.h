@@ -134,6 +134,11 @@ int vh_last_kernel_ms(vh_ctx* ctx, double* ms);
 int vh_profile_forward(vh_ctx* ctx, const float* in_nhwc_dev, int batch, float* logits_dev,
                        double* stage_ms, int n_stage_slots, int* n_stages_written);
 const char* vh_stage_name(int stage_index);
+/* Time every launch of ONE stage (index as in vh_stage_name; -1 = off) with hip events on the
+ * context's stream during the following vh_forward_device_async calls, then read the average /
+ * minimum launch duration and the number of launches measured. */
+int vh_set_stage_timing(vh_ctx* ctx, int stage_index);
+int vh_get_stage_timing(vh_ctx* ctx, double* avg_ms, double* min_ms, int* launches);
 
 /* debug taps: copy an internal activation of the LAST forward to the host as fp32.
  * what: 0 = residual stream x [batch*T, D] after the last layer run,

@@ -1,0 +1,148 @@
+// test_net_hip.cpp — drives hip::net_hip exactly the way an application of the reference drives
+// fpga::net_fpga: through a net::net_abstract*.  `cpu` runs the host-only checks (no device is
+// touched: construction, flatten order, get_net_data round trip, rule-of-five, stubs); `gpu` adds
+// launch_forward in MLP and ViT mode against the CPU oracle (linked here, in the TEST only).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <netHIP.h>
+#include <string>
+#include <vector>
+
+#include "../../oracle/oracle.h"
+
+static int failures = 0;
+#define CHECK(cond)                                                             \
+    do {                                                                        \
+        if (!(cond)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+static net::net_data make_net(size_t n_ins, const std::vector<size_t> &npl)
+{
+    net::net_data d;
+    d.n_ins = n_ins;
+    d.n_layers = npl.size();
+    d.n_p_l = npl;
+    float v = 0.f;
+    size_t fan = n_ins;
+    for (size_t l = 0; l < npl.size(); ++l)
+    {
+        d.params.emplace_back(npl[l], std::vector<float>(fan));
+        d.bias.emplace_back(npl[l]);
+        for (size_t j = 0; j < npl[l]; ++j)
+        {
+            for (size_t k = 0; k < fan; ++k) { d.params[l][j][k] = std::sin(v) * 0.3f; v += 1.f; }
+            d.bias[l][j] = std::cos(v) * 0.1f;
+        }
+        fan = npl[l];
+    }
+    return d;
+}
+
+static void host_checks()
+{
+    const net::net_data d = make_net(5, {4, 3, 2});
+    std::unique_ptr<net::net_abstract> net(new hip::net_hip(d, false, false));
+    hip::net_hip *h = static_cast<hip::net_hip *>(net.get());
+    // bookkeeping of netFPGA.cpp:68-76
+    CHECK(h->n_ins == 5 && h->n_layers == 3 && h->n_neurons == 9 && h->n_params == 5 * 4 + 4 * 3 + 3 * 2);
+    CHECK(h->n_p_l[0] == 4 && h->n_p_l[1] == 3 && h->n_p_l[2] == 2);
+    CHECK(h->activations == 1 && h->n_sets == 0 && !h->gradient_init);
+    CHECK(h->forward_performance == 0 && h->gradient_performance == 0 && !h->device_init);
+    // flatten order of netFPGA.cpp:91-106: layer-major, neuron-major, input-minor
+    CHECK(h->params[0] == d.params[0][0][0] && h->params[5] == d.params[0][1][0] && h->params[20] == d.params[1][0][0]);
+    CHECK(h->params[20 + 12 + 3] == d.params[2][1][0] && h->bias[4] == d.bias[1][0] && h->bias[8] == d.bias[2][1]);
+    // get_net_data is the exact inverse
+    const net::net_data r = net->get_net_data();
+    CHECK(r.n_ins == d.n_ins && r.n_layers == d.n_layers && r.n_p_l == d.n_p_l && r.params == d.params && r.bias == d.bias);
+    // stubs behave like the reference's
+    net->init_gradient(net::net_sets());
+    const std::vector<float> g = net->launch_gradient(7, 0.1f, 0.5f);
+    CHECK(g.size() == 7 && g[0] == 0.f && g[6] == 0.f);
+    net->print_inner_vals();
+    CHECK(net->get_forward_performance() == 0 && net->get_gradient_performance() == 0);
+    const net::image_set im = net->get_filtered_image();
+    CHECK(im.original_h == 1080 && im.original_w == 1920 && im.resized_image_data.empty());
+    // rule of five
+    hip::net_hip moved(std::move(*h));
+    CHECK(moved.n_params == 38 && moved.params[5] == d.params[0][1][0] && h->params == nullptr);
+    hip::net_hip other(make_net(2, {2}), false, false);
+    other = moved; // copy-assign: deep copy
+    CHECK(other.n_params == 38 && other.params != moved.params && other.params[20] == d.params[1][0][0] && other.n_p_l[2] == 2);
+    other = hip::net_hip(make_net(3, {1}), false, false); // move-assign
+    CHECK(other.n_params == 3 && other.n_layers == 1);
+    // random branch: the reference's formula and draw order on libc rand()
+    srand(1);
+    hip::net_hip rnd(make_net(5, {4, 3, 2}), false, true);
+    srand(1);
+    bool same = true;
+    for (int i = 0; i < rnd.n_params; ++i) same &= rnd.params[i] == float(rand() % 200 - 100) / 100;
+    for (int i = 0; i < rnd.n_neurons; ++i) same &= rnd.bias[i] == float(rand() % 200 - 100) / 100;
+    CHECK(same);
+    // bad input is reported, not UB
+    bool threw = false;
+    try { moved.launch_forward(std::vector<float>(4)); } catch (const std::exception &) { threw = true; }
+    CHECK(threw);
+    // ViT-mode construction is host-only too
+    vh_config c = {64, 16, 3, 128, 2, 256, 2, 40, VH_DTYPE_FP16, 2, 1e-6f, 0};
+    hip::net_hip vit(c, 11);
+    CHECK(vit.is_vit() && vit.n_ins == 64 * 64 * 3 && !vit.device_init && vit.vit_param_count() > 0);
+    threw = false;
+    c.dim = 100;
+    try { hip::net_hip bad(c, 1); } catch (const std::exception &) { threw = true; }
+    CHECK(threw);
+}
+
+static void gpu_checks()
+{
+    // ---- MLP mode vs oracle --------------------------------------------------------------
+    const net::net_data d = make_net(37, {64, 130, 5});
+    std::unique_ptr<net::net_abstract> net(new hip::net_hip(d, false, false));
+    hip::net_hip *h = static_cast<hip::net_hip *>(net.get());
+    std::vector<float> x(37);
+    for (int i = 0; i < 37; ++i) x[i] = std::sin(0.37f * i);
+    const std::vector<float> y = net->launch_forward(x);
+    std::vector<float> ref(5);
+    oracle_mlp_forward(h->n_ins, h->n_layers, h->n_p_l, h->params, h->bias, h->activations, x.data(), ref.data());
+    CHECK(y.size() == 5);
+    for (int i = 0; i < 5; ++i) CHECK(std::fabs(y[i] - ref[i]) <= 1e-5f * (1.f + std::fabs(ref[i])));
+    CHECK(net->get_forward_performance() > 0 && h->device_init);
+
+    // ---- ViT mode vs oracle ------------------------------------------------------------------
+    oracle_vit_config oc = {64, 16, 3, 128, 2, 256, 2, 40, 1e-6f};
+    vh_config c = {64, 16, 3, 128, 2, 256, 2, 40, VH_DTYPE_FP16, 1, 1e-6f, 0};
+    std::vector<char> blob(oracle_vit_blob_bytes(&oc));
+    CHECK(blob.size() == vh_weight_blob_bytes(&c));
+    oracle_vit_make_blob(&oc, 5, blob.data(), blob.size());
+    const int B = 3;
+    std::vector<float> img((size_t)B * 64 * 64 * 3), want((size_t)B * 40);
+    oracle_fill(img.data(), (int64_t)img.size(), 6, 0x100, 0, 0.f, 0.f);
+    oracle_vit_forward(&oc, blob.data(), img.data(), B, want.data(), nullptr, -1, 0);
+    std::unique_ptr<net::net_abstract> v(new hip::net_hip(c, blob.data(), blob.size()));
+    const std::vector<float> got = v->launch_forward(img); // batch 3 > max_batch 1: workspace grows
+    CHECK(got.size() == want.size());
+    float mx = 0.f, err = 0.f;
+    for (size_t i = 0; i < want.size(); ++i) { mx = std::fmax(mx, std::fabs(want[i])); err = std::fmax(err, std::fabs(got[i] - want[i])); }
+    printf("net_hip ViT fp16: max|d|/max|ref| = %.3e\n", err / mx);
+    CHECK(err / mx <= 1e-3f);
+    // seeded ViT: device generator == oracle generator, so logits must match the oracle's too
+    oracle_vit_make_blob(&oc, 77, blob.data(), blob.size());
+    oracle_vit_forward(&oc, blob.data(), img.data(), B, want.data(), nullptr, -1, 0);
+    hip::net_hip seeded(c, 77);
+    const std::vector<float> got2 = seeded.launch_forward(img);
+    err = 0.f; mx = 0.f;
+    for (size_t i = 0; i < want.size(); ++i) { mx = std::fmax(mx, std::fabs(want[i])); err = std::fmax(err, std::fabs(got2[i] - want[i])); }
+    CHECK(err / mx <= 1e-3f);
+    CHECK(seeded.get_forward_performance() > 0 && seeded.last_kernel_ms() > 0.0);
+}
+
+int main(int argc, char **argv)
+{
+    const std::string mode = argc > 1 ? argv[1] : "cpu";
+    host_checks();
+    if (mode == "gpu") gpu_checks();
+    printf("%s: %d failure(s)\n", mode.c_str(), failures);
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,78 @@
+"""CPU suite: the C-ABI library loads here (no GPU) and exports exactly what include/vithip.h
+declares; host-side argument checking works; compute entry points fail loudly without a device
+(there is no CPU fallback in the product path)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import vh_synth as S
+import vithip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vithip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    names = declared_symbols()
+    assert len(names) >= 40
+    out = subprocess.check_output(["nm", "-D", "--defined-only", vithip.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (vh_[a-z0-9_]+)", out))
+    assert set(names) <= exported, sorted(set(names) - exported)
+    assert set(names) == set(vithip.SYMBOLS), sorted(set(names) ^ set(vithip.SYMBOLS))
+    assert vithip.lib().vh_abi_version() == 1
+
+
+def test_no_torch_or_oracle_dependency_in_the_product_library():
+    out = subprocess.check_output(["readelf", "-d", vithip.LIB_PATH], text=True)
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any(("torch" in n) or ("oracle" in n) or ("c10" in n) for n in needed), needed
+    src = os.path.join(ROOT, "vit-fpga_amd")
+    for dirpath, _, files in os.walk(src):
+        for f in files:
+            if f.endswith((".hip", ".h", ".cpp", ".py")):
+                t = open(os.path.join(dirpath, f)).read()
+                for forbidden in ("liboracle", "oracle_lib", "oracle.h", "oracle_vit_", "oracle_mlp_"):
+                    assert forbidden not in t, (f, forbidden)
+
+
+def test_blob_size_and_config_validation_without_device():
+    L = vithip.lib()
+    for name in ("vit_micro", "vit_tiny", "vit_base", "vit_large_384"):
+        cfg = S.CONFIGS[name]
+        c = vithip.make_config(cfg, max_batch=4)
+        assert L.vh_weight_blob_bytes(C.byref(c)) == 64 + 4 * S.param_count(cfg)
+    bad = vithip.make_config(dict(S.CONFIGS["vit_micro"], dim=100))
+    assert L.vh_weight_blob_bytes(C.byref(bad)) == 0
+    bad = vithip.make_config(dict(S.CONFIGS["vit_micro"], classes=41))
+    assert L.vh_weight_blob_bytes(C.byref(bad)) == 0
+
+
+@pytest.mark.skipif(vithip.device_count() > 0, reason="checks the no-device behaviour")
+def test_compute_entry_points_fail_loudly_without_a_gpu():
+    with pytest.raises(vithip.VhError) as e:
+        vithip.VitContext(S.CONFIGS["vit_micro"])
+    assert e.value.code == 5  # VH_ERR_NO_DEVICE
+    with pytest.raises(vithip.VhError):
+        vithip.MlpContext(4, [3, 2])
+    with pytest.raises(vithip.VhError):
+        vithip.DeviceBuffer(1024)
+    with pytest.raises(vithip.VhError):
+        vithip.op_fill(None, 16, 1, 1, 0)
+
+
+def test_host_side_16bit_helpers():
+    x = np.array([1.0, 1.00390625, 1.01171875, -2.5, 0.0], dtype=np.float32)
+    assert np.array_equal(vithip.from16(vithip.to16(x, vithip.DTYPE_BF16), vithip.DTYPE_BF16),
+                          np.array([1.0, 1.0, 1.015625, -2.5, 0.0], dtype=np.float32))
+    assert np.array_equal(vithip.from16(vithip.to16(x, vithip.DTYPE_FP16), vithip.DTYPE_FP16)[:2],
+                          np.array([1.0, 1.00390625], dtype=np.float32))

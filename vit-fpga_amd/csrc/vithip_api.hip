@@ -138,6 +138,10 @@ struct vh_ctx {
     int64_t last_us = 0;
     bool timed = false;
     int last_batch = 0;
+    // optional per-launch timing of ONE stage inside the timed region (bench.py's roofline)
+    int timing_stage = -1;
+    std::vector<hipEvent_t> tev;  // pool: pairs (start, stop)
+    size_t tev_used = 0;
     std::string err;
 };
 
@@ -218,6 +222,17 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         GemmArgs g{a, w, bias, out, Mr, N, K, epi, aux, aux_i, f.dtype, 0};
         return launch_gemm(g, s);
     };
+    // hip events around every launch of the stage selected by vh_set_stage_timing()
+    auto tmark = [&](int stage) -> int {
+        if (stage != c->timing_stage) return VH_OK;
+        if (c->tev_used == c->tev.size()) {
+            hipEvent_t e;
+            HIPCHK(&c->err, hipEventCreate(&e));
+            c->tev.push_back(e);
+        }
+        HIPCHK(&c->err, hipEventRecord(c->tev[c->tev_used++], s));
+        return VH_OK;
+    };
     int rc;
     if ((rc = mark(-1))) return rc;
     HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, c->col16, f.dtype, s));
@@ -229,19 +244,33 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
     for (int l = 0; l < nl; ++l) {
         const LayerOff& o = L.layer[l];
+        if ((rc = tmark(ST_LN))) return rc;
         HIPCHK(&c->err, launch_layernorm(c->x, rows, D, D, P + o.ln1w, P + o.ln1b, f.ln_eps, c->xn16, f.dtype, s));
+        if ((rc = tmark(ST_LN))) return rc;
         if ((rc = mark(ST_LN))) return rc;
+        if ((rc = tmark(ST_QKV))) return rc;
         HIPCHK(&c->err, gemm(c->xn16, c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, c->qkv16, rows, 3 * D, D, VH_EPI_BIAS, nullptr, 0));
+        if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
+        if ((rc = tmark(ST_ATTN))) return rc;
         HIPCHK(&c->err, launch_attention(c->qkv16, batch, T, f.heads, c->att16, f.dtype, s));
+        if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
+        if ((rc = tmark(ST_PROJ))) return rc;
         HIPCHK(&c->err, gemm(c->att16, c->wo16[l], P + o.ob, c->x, rows, D, D, VH_EPI_BIAS_RESID, nullptr, 0));
+        if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
+        if ((rc = tmark(ST_LN))) return rc;
         HIPCHK(&c->err, launch_layernorm(c->x, rows, D, D, P + o.ln2w, P + o.ln2b, f.ln_eps, c->xn16, f.dtype, s));
+        if ((rc = tmark(ST_LN))) return rc;
         if ((rc = mark(ST_LN))) return rc;
+        if ((rc = tmark(ST_FC1))) return rc;
         HIPCHK(&c->err, gemm(c->xn16, c->w1_16[l], P + o.f1b, c->h16, rows, M, D, VH_EPI_BIAS_GELU, nullptr, 0));
+        if ((rc = tmark(ST_FC1))) return rc;
         if ((rc = mark(ST_FC1))) return rc;
+        if ((rc = tmark(ST_FC2))) return rc;
         HIPCHK(&c->err, gemm(c->h16, c->w2_16[l], P + o.f2b, c->x, rows, D, M, VH_EPI_BIAS_RESID, nullptr, 0));
+        if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
     }
     HIPCHK(&c->err, launch_layernorm(c->x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, c->clsn16, f.dtype, s));
@@ -379,6 +408,7 @@ int vh_destroy(vh_ctx* c) {
     if (c->arena) hipFree(c->arena);
     if (c->w16) hipFree(c->w16);
     if (c->blob) hipFree(c->blob);
+    for (hipEvent_t e : c->tev) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -484,6 +514,7 @@ int vh_forward_device_async(vh_ctx* c, const float* in, int batch, float* logits
     if (rc) return rc;
     if (steps <= 0) return fail(&c->err, VH_ERR_INVALID, "steps must be positive");
     HIPCHK(&c->err, hipSetDevice(c->device));
+    c->tev_used = 0;
     HIPCHK(&c->err, hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < steps; ++i)
         if ((rc = enqueue_forward(c, in, batch, logits, nullptr))) return rc;
@@ -573,6 +604,31 @@ int vh_profile_forward(vh_ctx* c, const float* in, int batch, float* logits, dou
     for (auto& p : ev) hipEventDestroy(p.second);
     if (n_written) *n_written = ST_COUNT;
     return rc;
+}
+
+int vh_set_stage_timing(vh_ctx* c, int stage) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    if (stage < -1 || stage >= ST_COUNT) return fail(&c->err, VH_ERR_INVALID, "unknown stage %d", stage);
+    c->timing_stage = stage;
+    c->tev_used = 0;
+    return VH_OK;
+}
+
+int vh_get_stage_timing(vh_ctx* c, double* avg_ms, double* min_ms, int* launches) {
+    if (!c || !avg_ms || !launches) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    double sum = 0.0, mn = 1e30;
+    int n = 0;
+    for (size_t i = 0; i + 1 < c->tev_used; i += 2) {
+        float t = 0.f;
+        HIPCHK(&c->err, hipEventElapsedTime(&t, c->tev[i], c->tev[i + 1]));
+        sum += t; if (t < mn) mn = t; ++n;
+    }
+    *avg_ms = n ? sum / n : 0.0;
+    if (min_ms) *min_ms = n ? mn : 0.0;
+    *launches = n;
+    return VH_OK;
 }
 
 int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {

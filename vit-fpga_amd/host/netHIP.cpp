@@ -1,0 +1,341 @@
+// netHIP.cpp — hip::net_hip: the host half of the drop-in for the reference's src/netFPGA.cpp.
+//
+// Compiled by plain g++ into libnetHIP.a (the counterpart of libnetFPGA.a, reference
+// Makefile:75); links against libvithip.so.  Reference behaviour each member mirrors is cited
+// inline as netFPGA.cpp:<line>.
+#include <netHIP.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <utility>
+
+namespace hip
+{
+    using namespace std;
+
+    namespace
+    {
+        const int IMAGE_HEIGHT = 1080; // netFPGA.h:14-15, only reported by get_filtered_image()
+        const int IMAGE_WIDTH = 1920;
+
+        size_t floats_per_image(const vh_config &c)
+        {
+            return (size_t)c.image_size * c.image_size * c.channels;
+        }
+    }
+
+    void net_hip::die(const char *what, const char *detail) const
+    {
+        string msg = string("net_hip: ") + what + ": " + (detail ? detail : "?");
+        const char *fatal = getenv("VH_FATAL");
+        if (fatal && fatal[0] == '1')
+        {
+            // the reference's convention: print, release, exit (checkError -> cleanup -> exit)
+            cerr << msg << "\n";
+            exit(1);
+        }
+        throw runtime_error(msg);
+    }
+
+    // ---- MLP-mode constructor: same bookkeeping and flatten order as netFPGA.cpp:58-109 ----
+    net_hip::net_hip(const net::net_data &data, bool derivate, bool random)
+        : n_ins((int)data.n_ins), n_layers((int)data.n_p_l.size()), n_p_l(nullptr), n_neurons(0), n_params(0),
+          params(nullptr), activations(VH_ACT_RELU2), bias(nullptr), n_sets(0), gradient_init(false),
+          gradient_performance(0), forward_performance(0), device_init(false), device(0), vit_mode(false),
+          vcfg(), vit_seed(0), mlp(nullptr), vit(nullptr)
+    {
+        (void)derivate; // ignored by the reference as well
+        if (n_layers <= 0 || n_ins <= 0)
+            die("constructor", "net_data needs n_ins > 0 and at least one layer");
+        n_p_l = new int[n_layers];
+        for (int l = 0; l < n_layers; l++)
+        {
+            n_p_l[l] = (int)data.n_p_l[l];
+            n_neurons += n_p_l[l];
+            n_params += n_p_l[l] * (l == 0 ? n_ins : n_p_l[l - 1]);
+        }
+        params = new DATA_TYPE[n_params];
+        bias = new DATA_TYPE[n_neurons];
+
+        if (random)
+        {
+            // value formula and draw order of the reference (netFPGA.cpp:82-88): libc rand(), no srand
+            for (int i = 0; i < n_params; i++)
+                params[i] = DATA_TYPE(rand() % 200 - 100) / 100;
+            for (int i = 0; i < n_neurons; i++)
+                bias[i] = DATA_TYPE(rand() % 200 - 100) / 100;
+            return;
+        }
+        int p = 0, q = 0;
+        for (int l = 0; l < n_layers; l++)
+        {
+            const int fan_in = (l == 0 ? n_ins : n_p_l[l - 1]);
+            if ((int)data.params.size() <= l || (int)data.params[l].size() != n_p_l[l] || (int)data.bias.size() <= l ||
+                (int)data.bias[l].size() != n_p_l[l])
+                die("constructor", "net_data.params / bias do not match n_p_l");
+            for (int j = 0; j < n_p_l[l]; j++)
+            {
+                if ((int)data.params[l][j].size() != fan_in)
+                    die("constructor", "net_data.params row length differs from the layer's fan-in");
+                memcpy(params + p, data.params[l][j].data(), sizeof(DATA_TYPE) * fan_in);
+                p += fan_in;
+                bias[q++] = data.bias[l][j];
+            }
+        }
+    }
+
+    // ---- ViT-mode constructors (host only; the device is touched in launch_forward) ----
+    net_hip::net_hip(const vh_config &cfg, uint64_t seed, int device_index)
+        : n_ins((int)floats_per_image(cfg)), n_layers(cfg.layers), n_p_l(nullptr), n_neurons(0), n_params(0), params(nullptr),
+          activations(VH_ACT_GELU), bias(nullptr), n_sets(0), gradient_init(false), gradient_performance(0),
+          forward_performance(0), device_init(false), device(device_index), vit_mode(true), vcfg(cfg), vit_seed(seed),
+          mlp(nullptr), vit(nullptr)
+    {
+        if (vh_weight_blob_bytes(&vcfg) == 0)
+            die("constructor", "unsupported vh_config");
+    }
+
+    net_hip::net_hip(const vh_config &cfg, const void *blob, size_t blob_bytes, int device_index)
+        : net_hip(cfg, 0, device_index)
+    {
+        if (!blob || blob_bytes != vh_weight_blob_bytes(&vcfg))
+            die("constructor", "weight blob size does not match vh_config");
+        vit_blob.assign((const char *)blob, blob_bytes);
+    }
+
+    void net_hip::release()
+    {
+        if (mlp)
+            vh_mlp_destroy(mlp);
+        if (vit)
+            vh_destroy(vit);
+        mlp = nullptr;
+        vit = nullptr;
+        device_init = false;
+        delete[] n_p_l;
+        delete[] params;
+        delete[] bias;
+        n_p_l = nullptr;
+        params = bias = nullptr;
+    }
+
+    net_hip::~net_hip() { release(); }
+
+    void net_hip::steal(net_hip &rh)
+    {
+        n_ins = rh.n_ins; n_layers = rh.n_layers; n_p_l = rh.n_p_l; n_neurons = rh.n_neurons; n_params = rh.n_params;
+        params = rh.params; activations = rh.activations; bias = rh.bias; n_sets = rh.n_sets;
+        gradient_init = rh.gradient_init; gradient_performance = rh.gradient_performance;
+        forward_performance = rh.forward_performance; device_init = rh.device_init; device = rh.device;
+        vit_mode = rh.vit_mode; vcfg = rh.vcfg; vit_seed = rh.vit_seed; vit_blob = std::move(rh.vit_blob);
+        mlp = rh.mlp; vit = rh.vit;
+        rh.n_p_l = nullptr; rh.params = nullptr; rh.bias = nullptr; rh.mlp = nullptr; rh.vit = nullptr;
+        rh.device_init = false;
+    }
+
+    void net_hip::copy_from(const net_hip &rh)
+    {
+        n_ins = rh.n_ins; n_layers = rh.n_layers; n_neurons = rh.n_neurons; n_params = rh.n_params;
+        activations = rh.activations; n_sets = rh.n_sets; gradient_init = rh.gradient_init;
+        gradient_performance = rh.gradient_performance; forward_performance = rh.forward_performance;
+        device = rh.device; vit_mode = rh.vit_mode; vcfg = rh.vcfg; vit_seed = rh.vit_seed; vit_blob = rh.vit_blob;
+        if (!vit_mode)
+        {
+            n_p_l = new int[n_layers];
+            params = new DATA_TYPE[n_params];
+            bias = new DATA_TYPE[n_neurons];
+            memcpy(n_p_l, rh.n_p_l, sizeof(int) * n_layers);
+            memcpy(params, rh.params, sizeof(DATA_TYPE) * n_params);
+            memcpy(bias, rh.bias, sizeof(DATA_TYPE) * n_neurons);
+        }
+        // device objects are re-created lazily by the copy's first launch_forward
+    }
+
+    net_hip::net_hip(net_hip &&rh)
+        : n_p_l(nullptr), params(nullptr), bias(nullptr), device_init(false), mlp(nullptr), vit(nullptr)
+    {
+        steal(rh);
+    }
+
+    net_hip &net_hip::operator=(net_hip &&rh)
+    {
+        if (this != &rh)
+        {
+            release();
+            steal(rh);
+        }
+        return *this;
+    }
+
+    net_hip &net_hip::operator=(const net_hip &rh)
+    {
+        if (this != &rh)
+        {
+            release();
+            copy_from(rh);
+        }
+        return *this;
+    }
+
+    // exact inverse of the MLP constructor (the reference's version is a broken TODO, netFPGA.cpp:206-237)
+    net::net_data net_hip::get_net_data()
+    {
+        net::net_data d;
+        d.n_ins = (size_t)n_ins;
+        d.n_layers = (size_t)n_layers;
+        if (vit_mode)
+            return d; // a ViT is not expressible as net_data; weights travel as the canonical blob
+        int p = 0, q = 0;
+        for (int l = 0; l < n_layers; l++)
+        {
+            const int fan_in = (l == 0 ? n_ins : n_p_l[l - 1]);
+            d.n_p_l.push_back((size_t)n_p_l[l]);
+            d.params.emplace_back();
+            d.bias.emplace_back();
+            for (int j = 0; j < n_p_l[l]; j++)
+            {
+                d.params[l].emplace_back(params + p, params + p + fan_in);
+                p += fan_in;
+                d.bias[l].push_back(bias[q++]);
+            }
+        }
+        return d;
+    }
+
+    void net_hip::set_activation(int code)
+    {
+        if (device_init)
+            die("set_activation", "must be called before the first launch_forward");
+        activations = code;
+    }
+
+    size_t net_hip::vit_param_count() const
+    {
+        return vit_mode ? (vh_weight_blob_bytes(&vcfg) - 64) / 4 : 0;
+    }
+
+    // lazy device init + weight upload: the roles of _init_program/_init_kernel/_load_params
+    // (netFPGA.cpp:242-260), done once per instance instead of via shared globals
+    void net_hip::ensure_device(int batch)
+    {
+        if (!vit_mode)
+        {
+            if (device_init)
+                return;
+            if (vh_mlp_create(device, n_ins, n_layers, n_p_l, activations, &mlp) != VH_OK)
+                die("vh_mlp_create", vh_last_error(nullptr));
+            if (vh_mlp_load_params(mlp, params, (size_t)n_params, bias, (size_t)n_neurons) != VH_OK)
+                die("vh_mlp_load_params", vh_mlp_last_error(mlp));
+            device_init = true;
+            return;
+        }
+        if (device_init && batch <= vcfg.max_batch)
+            return;
+        if (vit)
+        {
+            vh_destroy(vit); // grow the workspace for a larger batch
+            vit = nullptr;
+            device_init = false;
+        }
+        if (batch > vcfg.max_batch)
+            vcfg.max_batch = batch;
+        if (vh_create(&vcfg, device, &vit) != VH_OK)
+            die("vh_create", vh_last_error(nullptr));
+        const int rc = vit_blob.empty() ? vh_init_weights_seeded(vit, vit_seed)
+                                        : vh_load_weights(vit, vit_blob.data(), vit_blob.size());
+        if (rc != VH_OK)
+            die("weights", vh_last_error(vit));
+        device_init = true;
+    }
+
+    vector<DATA_TYPE> net_hip::launch_forward(const vector<DATA_TYPE> &inputs)
+    {
+        if (inputs.empty() || inputs.size() % (size_t)n_ins != 0)
+            die("launch_forward", "inputs.size() must be a positive multiple of n_ins");
+        const int count = (int)(inputs.size() / (size_t)n_ins);
+        ensure_device(count);
+#ifdef PERFORMANCE
+        const auto start = chrono::high_resolution_clock::now(); // same window as netFPGA.cpp:262-284
+#endif
+        vector<DATA_TYPE> out;
+        if (vit_mode)
+        {
+            out.resize((size_t)count * vcfg.classes);
+            if (vh_forward(vit, inputs.data(), count, out.data()) != VH_OK)
+                die("vh_forward", vh_last_error(vit));
+        }
+        else
+        {
+            out.resize((size_t)count * n_p_l[n_layers - 1]);
+            if (vh_mlp_forward(mlp, inputs.data(), count, out.data()) != VH_OK)
+                die("vh_mlp_forward", vh_mlp_last_error(mlp));
+        }
+#ifdef PERFORMANCE
+        forward_performance = chrono::duration_cast<chrono::microseconds>(chrono::high_resolution_clock::now() - start).count();
+#endif
+        return out;
+    }
+
+    double net_hip::last_kernel_ms()
+    {
+        double ms = 0.0;
+        if (vit && vh_last_kernel_ms(vit, &ms) == VH_OK)
+            return ms;
+        return 0.0;
+    }
+
+    // ---- training: stubs with the reference's observable behaviour (bodies commented out there) ----
+    void net_hip::init_gradient(const net::net_sets &sets) { (void)sets; } // netFPGA.cpp:518-542
+
+    vector<DATA_TYPE> net_hip::launch_gradient(size_t iterations, DATA_TYPE error_threshold, DATA_TYPE multiplier)
+    {
+        (void)error_threshold;
+        (void)multiplier;
+        return vector<DATA_TYPE>(iterations, 0); // netFPGA.cpp:579
+    }
+
+    void net_hip::print_inner_vals() {} // netFPGA.cpp:582-591
+
+    signed long net_hip::get_gradient_performance()
+    {
+#ifdef PERFORMANCE
+        return gradient_performance;
+#else
+        return 0;
+#endif
+    }
+
+    signed long net_hip::get_forward_performance()
+    {
+#ifdef PERFORMANCE
+        return forward_performance;
+#else
+        return 0;
+#endif
+    }
+
+    // ---- image filter: out of scope (kernel `image_process` absent) ----
+    // Behaves like the reference with an empty ring: submissions are dropped with the reference's
+    // own overflow message, reads return an empty 1080x1920 image_set with its underflow message
+    // (netFPGA.cpp:330-333, 358-361).
+    void net_hip::filter_image(const net::image_set &set)
+    {
+        (void)set;
+        cout << "PILA LLENA\n";
+    }
+
+    net::image_set net_hip::get_filtered_image()
+    {
+        net::image_set out;
+        out.original_x_pos = 0;
+        out.original_y_pos = 0;
+        out.original_h = IMAGE_HEIGHT;
+        out.original_w = IMAGE_WIDTH;
+        cout << "PILA VACIA\n";
+        return out;
+    }
+}

@@ -65,6 +65,8 @@ SYMBOLS = {
     "vh_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double)]),
     "vh_profile_forward": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_double), _i, _pi]),
     "vh_stage_name": (C.c_char_p, [_i]),
+    "vh_set_stage_timing": (_i, [_vp, _i]),
+    "vh_get_stage_timing": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _pi]),
     "vh_debug_read": (_i, [_vp, _i, _vp, _sz]),
     "vh_debug_set_layers": (_i, [_vp, _i]),
     "vh_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp]),
@@ -249,6 +251,14 @@ class VitContext:
         nw = C.c_int(0)
         _check(lib().vh_profile_forward(self.h, in_ptr, batch, out_ptr, arr, 2 * n, C.byref(nw)), self.h)
         return {STAGES[i]: (arr[i], int(arr[n + i])) for i in range(n)}
+
+    def set_stage_timing(self, stage_name):
+        _check(lib().vh_set_stage_timing(self.h, STAGES.index(stage_name) if stage_name else -1), self.h)
+
+    def get_stage_timing(self):
+        avg, mn, n = C.c_double(0), C.c_double(0), C.c_int(0)
+        _check(lib().vh_get_stage_timing(self.h, C.byref(avg), C.byref(mn), C.byref(n)), self.h)
+        return avg.value, mn.value, n.value
 
     def debug_read(self, what, n_floats):
         out = np.empty(n_floats, dtype=np.float32)
