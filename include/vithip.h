@@ -179,6 +179,11 @@ int vh_op_cast(const float* in_dev, void* out16_dev, int64_t n, int dtype, void*
 int vh_op_fill(float* out_dev, int64_t n, uint64_t seed, uint32_t tensor_id, int kind,
                float sigma, void* stream);
 
+/* micro-benchmark: average device time (ms) of one launch of the GEMM kernel on synthetic operands
+ * generated in HBM (uniform[-1,1) activations, sigma=0.02 weights), `iters` launches between events */
+int vh_bench_gemm(int device, int64_t M, int N, int K, int epilogue, int dtype, int variant, int iters,
+                  double* avg_ms);
+
 /* ---- MLP mode: the reference's actual launch_forward semantics -------------------------- */
 /* y_l = act(W_l y_{l-1} + b_l), weights row-major [n_out, n_in] per layer, layers and biases
  * concatenated exactly as the ctor flattens them (netFPGA.cpp:68-76, 91-106); kernel

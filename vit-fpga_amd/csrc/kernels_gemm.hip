@@ -24,6 +24,7 @@
 //   * 1-D grid remapped so that the workgroups that share an XCD (blockIdx % 8) walk a
 //     contiguous run of tiles, n fastest: neighbours reuse the same A panel from that XCD's L2.
 //   * ragged M / N: loads clamp the row index, stores are predicated (N % 4 == 0, K % 64 == 0).
+#include "gemm_epilogue.h"
 #include "vh_kernels.h"
 
 namespace vh {
@@ -126,45 +127,8 @@ gemm_nt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     }
 
     // ---- epilogue: lane owns rows m = .. + (lane&15), 4 consecutive columns n = .. + 4*(lane>>4)
-    const int m0 = tile_m * BM + wm * TM + frow;
-    const int n0 = tile_n * BN + wn * TN + fq * 4;
-    f32x4 bv[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + ni * 16;
-        bv[ni] = (n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + mi * 16;
-        if (m >= M) continue;
-        int64_t orow = m;
-        const float* posrow = nullptr;
-        if constexpr (EPI == VH_EPI_PATCH) {
-            const int img = m / aux_i, p = m - img * aux_i;
-            orow = (int64_t)img * (aux_i + 1) + 1 + p;
-            posrow = aux + (int64_t)(1 + p) * N;
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + ni * 16;
-            if (n >= N) continue;
-            f32x4 v = acc[mi][ni] + bv[ni];
-            if constexpr (EPI == VH_EPI_BIAS) {
-                *(typename T::vec4*)((elem*)outp + orow * N + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-            } else if constexpr (EPI == VH_EPI_BIAS_GELU) {
-                *(typename T::vec4*)((elem*)outp + orow * N + n) =
-                    pack4<T>(gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3]));
-            } else if constexpr (EPI == VH_EPI_BIAS_RESID) {
-                f32x4* p = (f32x4*)((float*)outp + orow * N + n);
-                *p = *p + v;
-            } else if constexpr (EPI == VH_EPI_BIAS_F32) {
-                *(f32x4*)((float*)outp + orow * N + n) = v;
-            } else {  // VH_EPI_PATCH
-                *(f32x4*)((float*)outp + orow * N + n) = v + *(const f32x4*)(posrow + n);
-            }
-        }
-    }
+    gemm_epilogue<T, EPI, MI, NI>(acc, bias, outp, M, N, tile_m * BM + wm * TM, tile_n * BN + wn * TN, lane, aux, aux_i,
+                                  (tile_m + 1) * BM <= M && (tile_n + 1) * BN <= N, smem, wave);
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -186,7 +150,15 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
 }
 
 template <typename T, int EPI>
+hipError_t launch_gemm_pipelined(const GemmArgs& g, int variant, hipStream_t s);  // kernels_gemm3.hip
+
+template <typename T, int EPI>
+hipError_t launch_gemm_pingpong(const GemmArgs& g, hipStream_t s);  // kernels_gemm5.hip
+
+template <typename T, int EPI>
 static hipError_t launch_tile(const GemmArgs& g, int variant, hipStream_t s) {
+    if (variant == 5) return launch_gemm_pingpong<T, EPI>(g, s);
+    if (variant >= 3) return launch_gemm_pipelined<T, EPI>(g, variant, s);
     if (variant == 2) return launch_one<T, 256, 256, 2, 4, EPI>(g, s);
     return launch_one<T, 128, 128, 2, 2, EPI>(g, s);
 }
@@ -216,7 +188,8 @@ const char* gemm_check(const GemmArgs& g) {
     if (g.epilogue < 0 || g.epilogue > VH_EPI_PATCH) return "gemm: unknown epilogue";
     if (g.epilogue == VH_EPI_PATCH && (!g.aux || g.aux_i <= 0)) return "gemm: EPI_PATCH needs pos-emb and patches/image";
     if (g.dtype != VH_DTYPE_BF16 && g.dtype != VH_DTYPE_FP16) return "gemm: dtype";
-    if (g.variant < 0 || g.variant > 2) return "gemm: variant";
+    if (g.variant < 0 || g.variant > 5) return "gemm: variant";
+    if ((g.variant == 3 || g.variant == 4) && g.K % 32) return "gemm: K must be a multiple of 32";
     if (!g.a || !g.w || !g.bias || !g.out) return "gemm: null pointer";
     return nullptr;
 }

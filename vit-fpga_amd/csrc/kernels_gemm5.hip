@@ -1,0 +1,201 @@
+// kernels_gemm5.hip — the ping-pong GEMM of the ViT hot path (gfx950), variant 5.
+//
+// Same contract, operands, swizzled BK=64 LDS image and fused epilogues as kernels_gemm.hip; 256x256 tile,
+// 8 waves, two 64 KiB stages.  What changes is WHO uses the matrix pipe WHEN.
+//
+// Ablation of the plain two-stage loop (tools/diag_gemm.hip, QKV shape) showed its three costs ADD instead
+// of overlapping: MFMA only 180 us, DMA only 176 us, MFMA + fragment reads 239 us, all three 310 us —
+// because all 8 waves run [barrier, issue DMA, read fragments, MFMA] in lockstep, so each SIMD's matrix pipe
+// idles whenever its two waves are both loading.  Here the two waves of a SIMD work in opposite phases:
+//
+//   wave group G0 = waves 0-3 (tile rows 0..127), G1 = waves 4-7 (rows 128..255); wave i and i+4 share a SIMD.
+//   per K-tile a wave runs four phases, each closed by s_barrier:   L0  C0  L1  C1
+//      L0: ds_read W fragments (both k-steps) + X fragments of k-step 0, issue DMA of its A half of tile k+1
+//      C0: 32 MFMAs (k-step 0)
+//      L1: ds_read X fragments of k-step 1, issue DMA of its W half of tile k+2
+//      C1: 32 MFMAs (k-step 1)
+//   G1 runs one phase behind G0 (one extra barrier up front), so in every phase one wave of each SIMD
+//   multiplies while the other reads LDS and feeds the DMA queue.
+//
+// Hazard bookkeeping (p = global phase; G0: L0 4k, C0 4k+1, L1 4k+2, C1 4k+3; G1: +1):
+//   * every L phase ends with lgkmcnt(0) before its barrier  => reads issued in phase p are complete for
+//     everybody after the barrier that closes p.
+//   * RAW (DMA -> ds_read): the issuing wave's counted vmcnt, then a barrier the readers pass.
+//       end of L1(k): vmcnt(8|4|0) -> this wave's W half of tile k+1 landed   (read from p = 4k+4)
+//       end of C1(k): vmcnt(4|0)   -> this wave's A half of tile k+1 landed   (read by its own group)
+//   * WAR (ds_read -> DMA): W of a stage is read only in L0 (both groups: phases 4k, 4k+1), refilled from
+//     L1 (4k+2 / 4k+3); a group's A half is read in its L0/L1 and refilled by the same group in its next L0.
+//   DMA of a tile is in flight for >= 4 phases (~2000 cycles) before it is needed; the waits are counted, the
+//   barriers raw, so later tiles' DMA stays in flight across them.
+#include "gemm_epilogue.h"
+#include "vh_kernels.h"
+
+namespace vh {
+
+template <int N>
+__device__ __forceinline__ void pp_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int EPI>
+__global__ void __launch_bounds__(512, 2)
+gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W,
+                  const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
+                  const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n) {
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int STAGE_BYTES = 65536, W_OFF = 32768;
+    constexpr int MI = 8, NI = 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+
+    // ---- DMA: this wave moves 4 x 1 KiB of its group's A half and 4 x 1 KiB of its group's W half -------
+    const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+    const elem *gA[4], *gW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = grp * 128 + (i * 4 + wn) * 8 + lr;
+        int ra = tile_m * BM + r, rw = tile_n * BN + r;
+        ra = ra < M ? ra : M - 1;
+        rw = rw < N ? rw : N - 1;
+        gA[i] = A + (int64_t)ra * K + lc * 8;
+        gW[i] = W + (int64_t)rw * K + lc * 8;
+    }
+    const int dma_off = grp * 16384 + wn * 1024;  // + i * 4096
+    auto issue_a = [&](int kt) {
+        char* dst = smem + (kt & 1) * STAGE_BYTES + dma_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gA[i] + kt * BK),
+                                             (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
+    };
+    auto issue_w = [&](int kt) {
+        char* dst = smem + (kt & 1) * STAGE_BYTES + W_OFF + dma_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gW[i] + kt * BK),
+                                             (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
+    };
+
+    // ---- fragment addresses ----------------------------------------------------------------------------------
+    const int frow = lane & 15, fq = lane >> 4;
+    const int off0 = frow * 128 + (((0 | fq) ^ (frow & 7)) << 4);
+    const int off1 = frow * 128 + (((4 | fq) ^ (frow & 7)) << 4);
+    const int xbase = grp * 16384;          // rows 128*grp ..
+    const int wbase = W_OFF + wn * 8192;    // rows 64*wn ..
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    vec8 wf0[NI], wf1[NI], xf[MI];
+
+    const int nk = K / BK;
+
+    // ---- prologue: tiles 0 and 1 ---------------------------------------------------------------------------------
+    issue_w(0);
+    issue_a(0);
+    if (nk > 1) {
+        issue_w(1);
+        issue_a(1);
+        pp_wait_vmcnt<8>();
+    } else {
+        pp_wait_vmcnt<0>();
+    }
+    pp_barrier();             // tile 0 visible
+    if (grp == 1) pp_barrier();  // G1 runs one phase behind
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* st = smem + (kt & 1) * STAGE_BYTES;
+        // ---- L0 ------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            wf0[ni] = *(const vec8*)(st + wbase + ni * 2048 + off0);
+            wf1[ni] = *(const vec8*)(st + wbase + ni * 2048 + off1);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off0);
+        if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        pp_barrier();
+        // ---- C0 ------------------------------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf0[ni], xf[mi], acc[mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        pp_barrier();
+        // ---- L1 ------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off1);
+        if (kt + 2 < nk) {
+            issue_w(kt + 2);
+            pp_wait_vmcnt<8>();
+        } else if (kt + 1 < nk) {
+            pp_wait_vmcnt<4>();
+        } else {
+            pp_wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        pp_barrier();
+        // ---- C1 ------------------------------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf1[ni], xf[mi], acc[mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        if (kt + 2 < nk) pp_wait_vmcnt<4>();
+        else pp_wait_vmcnt<0>();
+        pp_barrier();
+    }
+    if (grp == 0) pp_barrier();  // G0 waits for G1's last phase
+
+    gemm_epilogue<T, EPI, MI, NI>(acc, bias, outp, M, N, tile_m * BM + grp * 128, tile_n * BN + wn * 64, lane, aux, aux_i,
+                                  (tile_m + 1) * BM <= M && (tile_n + 1) * BN <= N, smem, wave);
+}
+
+template <typename T, int EPI>
+hipError_t launch_gemm_pingpong(const GemmArgs& g, hipStream_t s) {
+    const int tiles_m = (int)((g.M + 255) / 256), tiles_n = (g.N + 255) / 256;
+    constexpr size_t lds = 131072;
+    auto k = gemm_nt_pp_kernel<T, EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(tiles_m * tiles_n), dim3(512), lds, s, (const typename T::elem*)g.a,
+                       (const typename T::elem*)g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+#define VH_INST(T)                                                                               \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS>(const GemmArgs&, hipStream_t);       \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_GELU>(const GemmArgs&, hipStream_t);  \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_RESID>(const GemmArgs&, hipStream_t); \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_F32>(const GemmArgs&, hipStream_t);   \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_PATCH>(const GemmArgs&, hipStream_t);
+VH_INST(BF16)
+VH_INST(FP16)
+
+}  // namespace vh

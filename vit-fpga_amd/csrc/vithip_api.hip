@@ -711,6 +711,55 @@ int vh_op_fill(float* out, int64_t n, uint64_t seed, uint32_t tensor_id, int kin
     return VH_OK;
 }
 
+// micro-benchmark of one GEMM shape: synthetic operands generated in HBM, `iters` back-to-back
+// launches between two hip events; returns the average launch time
+int vh_bench_gemm(int device, int64_t M, int N, int K, int epilogue, int dtype, int variant, int iters, double* avg_ms) {
+    if (!avg_ms || iters <= 0) return fail(nullptr, VH_ERR_INVALID, "vh_bench_gemm: bad argument");
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    float *a32 = nullptr, *w32 = nullptr, *bias = nullptr, *aux = nullptr;
+    void *a16 = nullptr, *w16 = nullptr, *out = nullptr;
+    const int aux_i = 196;
+    const size_t out_rows = epilogue == VH_EPI_PATCH ? (size_t)(M / aux_i + 1) * (aux_i + 1) : (size_t)M;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        hipFree(a32); hipFree(w32); hipFree(bias); hipFree(aux); hipFree(a16); hipFree(w16); hipFree(out);
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+    };
+#define BCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(nullptr, VH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    BCHK(hipMalloc((void**)&a32, (size_t)M * K * 4));
+    BCHK(hipMalloc((void**)&w32, (size_t)N * K * 4));
+    BCHK(hipMalloc((void**)&bias, (size_t)N * 4));
+    BCHK(hipMalloc((void**)&aux, (size_t)(aux_i + 1) * N * 4));
+    BCHK(hipMalloc(&a16, (size_t)M * K * 2));
+    BCHK(hipMalloc(&w16, (size_t)N * K * 2));
+    BCHK(hipMalloc(&out, out_rows * N * 4));
+    BCHK(hipMemset(out, 0, out_rows * N * 4));
+    BCHK(launch_fill(a32, (int64_t)M * K, 1, 1, 0, 0.f, 0.f, nullptr));
+    BCHK(launch_fill(w32, (int64_t)N * K, 1, 2, 1, 0.02f, 0.f, nullptr));
+    BCHK(launch_fill(bias, N, 1, 3, 1, 0.02f, 0.f, nullptr));
+    BCHK(launch_fill(aux, (int64_t)(aux_i + 1) * N, 1, 4, 1, 0.02f, 0.f, nullptr));
+    BCHK(launch_cast(a32, a16, (int64_t)M * K, dtype, nullptr));
+    BCHK(launch_cast(w32, w16, (int64_t)N * K, dtype, nullptr));
+    GemmArgs g{a16, w16, bias, out, M, N, K, epilogue, aux, aux_i, dtype, variant};
+    if (const char* why = gemm_check(g)) { cleanup(); return fail(nullptr, VH_ERR_INVALID, "%s", why); }
+    BCHK(hipEventCreate(&e0));
+    BCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) BCHK(launch_gemm(g, nullptr));
+    BCHK(hipDeviceSynchronize());
+    BCHK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) BCHK(launch_gemm(g, nullptr));
+    BCHK(hipEventRecord(e1, nullptr));
+    BCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    BCHK(hipEventElapsedTime(&ms, e0, e1));
+#undef BCHK
+    *avg_ms = ms / iters;
+    cleanup();
+    return VH_OK;
+}
+
 // ---- MLP mode ------------------------------------------------------------------------------------
 int vh_mlp_create(int device, int n_ins, int n_layers, const int* n_p_l, int activation, vh_mlp** out) {
     if (!out || !n_p_l || n_ins <= 0 || n_layers <= 0) return fail(nullptr, VH_ERR_INVALID, "vh_mlp_create: bad argument");

@@ -75,6 +75,7 @@ SYMBOLS = {
     "vh_op_im2col": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "vh_op_cast": (_i, [_vp, _vp, _i64, _i, _vp]),
     "vh_op_fill": (_i, [_vp, _i64, _u64, C.c_uint32, _i, _f, _vp]),
+    "vh_bench_gemm": (_i, [_i, _i64, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_double)]),
     "vh_mlp_create": (_i, [_i, _i, _i, _pi, _i, C.POINTER(_vp)]),
     "vh_mlp_load_params": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vh_mlp_forward": (_i, [_vp, _vp, _i, _vp]),
@@ -310,6 +311,13 @@ class MlpContext:
 # ---- operator-level wrappers (device pointers in, nothing hidden) ------------------------------------
 def op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, dtype, aux_ptr=None, aux_i=0, variant=0):
     _check(lib().vh_op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, aux_ptr, aux_i, dtype, variant, None))
+
+
+def bench_gemm(M, N, K, epilogue, dtype=DTYPE_BF16, variant=0, iters=20, device=0):
+    """Average launch time in ms of one GEMM shape (synthetic operands generated in HBM)."""
+    ms = C.c_double(0)
+    _check(lib().vh_bench_gemm(device, M, N, K, epilogue, dtype, variant, iters, C.byref(ms)))
+    return ms.value
 
 
 def op_layernorm(x_ptr, rows, dim, row_stride, gamma_ptr, beta_ptr, eps, out_ptr, dtype):
