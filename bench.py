@@ -142,7 +142,7 @@ def main():
                        "parallelism": f"image-sharded x{world}, weights RCCL-broadcast once, no data-path collective",
                        "flop_per_image": flops_img},
             "forward_mfma_frac": round(ips / world * flops_img / (peak * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<256x256x64, bias+GELU> (fc1)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_pp_kernel<bias+GELU> 256x256x64 ping-pong (fc1)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,
                          "flop_per_launch": fc1_flops, "avg_launch_ms": round(fc1_avg_ms, 5),
@@ -175,7 +175,7 @@ def cpu_baseline(cfg, target_seconds):
     t = time.perf_counter()
     O.vit_forward(cfg, blob, probe, threads=cores)
     per_img = (time.perf_counter() - t) / 2
-    n = int(max(2, min(64, target_seconds / max(per_img, 1e-6))))
+    n = int(max(2, min(512, target_seconds / max(per_img, 1e-6))))
     imgs = S.make_images(cfg, 1, n)
     t = time.perf_counter()
     O.vit_forward(cfg, blob, imgs, threads=cores)

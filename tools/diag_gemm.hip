@@ -104,6 +104,21 @@ k(const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __res
             }
         return;
     }
+    if (DIAG & (32 | 64 | 128)) {  // row-major output, 16 B per lane: 128 B (32), 512 B (64) or 256 B (128) per row per instruction
+        typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+#pragma unroll
+        for (int i = 0; i < MI * NI / 2; ++i) {
+            f32x4 v = acc[i / 2][(i & 1) * 2] + acc[i / 2][(i & 1) * 2 + 1];
+            b8 o;
+            for (int j = 0; j < 4; ++j) { o[j] = (__bf16)v[j]; o[4 + j] = (__bf16)v[3 - j]; }
+            int row, colb;
+            if (DIAG & 32) { row = tile_m * BM + wm * TM + i * 8 + (lane >> 3); colb = (tile_n * BN + wn * TN) * 2 + (lane & 7) * 16; }
+            else if (DIAG & 64) { row = tile_m * BM + wave * 32 + i * 2 + (lane >> 5); colb = tile_n * BN * 2 + (lane & 31) * 16; }
+            else { row = tile_m * BM + wm * TM + (wn >> 1) * 64 + i * 4 + (lane >> 4); colb = (tile_n * BN + (wn & 1) * 128) * 2 + (lane & 15) * 16; }
+            if (row < M) *(b8*)((char*)out + (int64_t)row * N * 2 + colb) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + mi * 16;
@@ -163,6 +178,9 @@ int main() {
         R(0, "baseline")
         R(8, "no epilogue stores")
         R(16, "ideal coalesced stores")
+        R(32, "row-major 128 B/row/instr")
+        R(128, "row-major 256 B/row/instr")
+        R(64, "row-major 512 B/row/instr")
         R(1, "no DMA in loop")
         R(9, "no DMA, no stores")
         R(2, "no MFMA")

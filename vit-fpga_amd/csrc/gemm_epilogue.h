@@ -14,16 +14,17 @@ namespace vh {
 // orders of magnitude below the 16-bit rounding of the GELU output).  ~17 VALU ops per element
 // instead of ~45 for libm's erff: the fc1 epilogue evaluates 128 of these per lane per tile.
 __device__ __forceinline__ float gelu_fast(float v) {
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
+    // with x = |v|/sqrt(2): h = 0.5*erfc(x) = 0.5*poly(t)*t*exp(-x^2), t = 1/(1 + 0.3275911 x);
+    // gelu(v) = v*Phi(v) = max(v,0) - |v|*h   (both signs; no cancellation for v << 0).  13 VALU ops.
+    const float u = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418882f, u, 1.0f));
+    float p = fmaf(0.5307027145f, t, -0.7265760135f);
+    p = fmaf(p, t, 0.7107068705f);
+    p = fmaf(p, t, -0.142248368f);
+    p = fmaf(p, t, 0.127414796f);
     p *= t;
-    const float e = p * __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);  // erfc(x), x >= 0
-    const float phi = v < 0.f ? 0.5f * e : 1.0f - 0.5f * e;
-    return v * phi;
+    const float h = p * __builtin_amdgcn_exp2f(v * v * -0.72134752044f);
+    return fmaf(-u, h, fmaxf(v, 0.f));
 }
 
 template <typename T, int EPI, int MI, int NI, bool GUARD>
@@ -78,11 +79,13 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
 // 128-B (16-bit) or 256-B (fp32) row segments, 16 B per lane.  Only one workgroup barrier is needed
 // (before the first LDS write: other waves may still be reading the last stage); write -> read-back is
 // wave-private.  `sw` = this wave's slice, m_w/n_w = first row/column of the wave's sub-tile.
-template <typename T, int EPI, int MI, int NI>
+// SMI = 16-row blocks staged per pass for 16-bit output (slice = SMI*2 KiB per wave); fp32 stages SMI/2.
+template <typename T, int EPI, int MI, int NI, int SMI = MI>
 __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI], const float* __restrict__ bias,
                                                      void* __restrict__ outp, int N, int m_w, int n_w, int lane,
                                                      char* sw) {
     static_assert(NI == 4, "staged epilogue assumes a 64-column wave tile");
+    static_assert(MI % SMI == 0 && SMI % 2 == 0, "slice must divide the wave tile");
     using elem = typename T::elem;
     const int frow = lane & 15, fq = lane >> 4;
     f32x4 bv[NI];
@@ -91,45 +94,49 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
 
     if constexpr (EPI == VH_EPI_BIAS || EPI == VH_EPI_BIAS_GELU) {
         // rows of 64 x 16-bit = 128 B = 8 chunks of 16 B; chunk c of row r lives at chunk c ^ (r & 7)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int r = mi * 16 + frow;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                f32x4 v = acc[mi][ni] + bv[ni];
-                if constexpr (EPI == VH_EPI_BIAS_GELU) {
-                    v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
-                }
-                const int c = ni * 2 + (fq >> 1);
-                *(typename T::vec4*)(sw + r * 128 + ((c ^ (r & 7)) << 4) + (fq & 1) * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
-            }
-        }
         const int rr = lane >> 3, pc = lane & 7;
 #pragma unroll
-        for (int i = 0; i < MI * 2; ++i) {
-            const int r = i * 8 + rr;
-            const u32x4 v = *(const u32x4*)(sw + r * 128 + (pc << 4));
-            const int n = n_w + ((pc ^ (r & 7)) << 3);
-            *(u32x4*)((elem*)outp + (int64_t)(m_w + r) * N + n) = v;
+        for (int h = 0; h < MI / SMI; ++h) {
+#pragma unroll
+            for (int mi = 0; mi < SMI; ++mi) {
+                const int r = mi * 16 + frow;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    f32x4 v = acc[h * SMI + mi][ni] + bv[ni];
+                    if constexpr (EPI == VH_EPI_BIAS_GELU) {
+                        v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
+                    }
+                    const int c = ni * 2 + (fq >> 1);
+                    *(typename T::vec4*)(sw + r * 128 + ((c ^ (r & 7)) << 4) + (fq & 1) * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SMI * 2; ++i) {
+                const int r = i * 8 + rr;
+                const u32x4 v = *(const u32x4*)(sw + r * 128 + (pc << 4));
+                const int n = n_w + ((pc ^ (r & 7)) << 3);
+                *(u32x4*)((elem*)outp + (int64_t)(m_w + h * SMI * 16 + r) * N + n) = v;
+            }
         }
     } else {
-        // fp32 out: two passes of MI/2 row blocks; rows of 64 floats = 256 B = 16 chunks, chunk ^ (r & 15)
+        // fp32 out: rows of 64 floats = 256 B = 16 chunks, chunk ^ (r & 15); SMI/2 row blocks per pass
+        constexpr int FMI = SMI / 2;
         const int rr = lane >> 4, pc = lane & 15;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < MI / FMI; ++h) {
 #pragma unroll
-            for (int mi = 0; mi < MI / 2; ++mi) {
+            for (int mi = 0; mi < FMI; ++mi) {
                 const int r = mi * 16 + frow;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    *(f32x4*)(sw + r * 256 + (((ni * 4 + fq) ^ (r & 15)) << 4)) = acc[h * (MI / 2) + mi][ni] + bv[ni];
+                    *(f32x4*)(sw + r * 256 + (((ni * 4 + fq) ^ (r & 15)) << 4)) = acc[h * FMI + mi][ni] + bv[ni];
             }
 #pragma unroll
-            for (int i = 0; i < MI * 2; ++i) {
+            for (int i = 0; i < FMI * 4; ++i) {
                 const int r = i * 4 + rr;
                 f32x4 v = *(const f32x4*)(sw + r * 256 + (pc << 4));
                 const int n = n_w + ((pc ^ (r & 15)) << 2);
-                f32x4* p = (f32x4*)((float*)outp + (int64_t)(m_w + h * (MI / 2) * 16 + r) * N + n);
+                f32x4* p = (f32x4*)((float*)outp + (int64_t)(m_w + h * FMI * 16 + r) * N + n);
                 if constexpr (EPI == VH_EPI_BIAS_RESID) v = v + *p;
                 *p = v;
             }
@@ -139,17 +146,17 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
 
 // Full tiles (the common case) take the staged, unpredicated path; ragged tiles and the patch-row remap
 // store directly with per-element predicates.  `smem`/`wave_slice_bytes`: the kernel's dynamic LDS, which
-// must hold NW * wave_slice_bytes (TM * 128 B per wave).  Contains a workgroup barrier: call it from
-// uniform control flow only.
-template <typename T, int EPI, int MI, int NI>
+// must hold NW * SMI * 2 KiB from `smem` on.  With BARRIER it contains a workgroup barrier (needed when other
+// waves may still be reading the operand stages): call it from uniform control flow only.
+template <typename T, int EPI, int MI, int NI, int SMI = MI, bool BARRIER = true>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const float* __restrict__ bias,
                                               void* __restrict__ outp, int M, int N, int m_w, int n_w, int lane,
                                               const float* __restrict__ aux, int aux_i, bool tile_is_full, char* smem,
                                               int wave) {
     if constexpr (EPI != VH_EPI_PATCH) {
         if (tile_is_full) {
-            __syncthreads();
-            gemm_epilogue_staged<T, EPI, MI, NI>(acc, bias, outp, N, m_w, n_w, lane, smem + wave * (MI * 16 * 128));
+            if constexpr (BARRIER) __syncthreads();
+            gemm_epilogue_staged<T, EPI, MI, NI, SMI>(acc, bias, outp, N, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
             return;
         }
     }

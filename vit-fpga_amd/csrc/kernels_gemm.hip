@@ -153,11 +153,11 @@ template <typename T, int EPI>
 hipError_t launch_gemm_pipelined(const GemmArgs& g, int variant, hipStream_t s);  // kernels_gemm3.hip
 
 template <typename T, int EPI>
-hipError_t launch_gemm_pingpong(const GemmArgs& g, hipStream_t s);  // kernels_gemm5.hip
+hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t s);  // kernels_gemm5.hip
 
 template <typename T, int EPI>
 static hipError_t launch_tile(const GemmArgs& g, int variant, hipStream_t s) {
-    if (variant == 5) return launch_gemm_pingpong<T, EPI>(g, s);
+    if (variant == 5 || variant == 6) return launch_gemm_pingpong<T, EPI>(g, variant == 6, s);
     if (variant >= 3) return launch_gemm_pipelined<T, EPI>(g, variant, s);
     if (variant == 2) return launch_one<T, 256, 256, 2, 4, EPI>(g, s);
     return launch_one<T, 128, 128, 2, 2, EPI>(g, s);
@@ -177,7 +177,7 @@ static hipError_t launch_epi(const GemmArgs& g, int variant, hipStream_t s) {
 
 int gemm_pick_variant(int64_t M, int N) {
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-    return t256 >= 256 ? 2 : 1;  // the 256x256 tile only when it still fills all 256 CUs
+    return t256 >= 256 ? 5 : 1;  // the 256x256 ping-pong kernel only when it still fills all 256 CUs
 }
 
 const char* gemm_check(const GemmArgs& g) {
@@ -188,7 +188,7 @@ const char* gemm_check(const GemmArgs& g) {
     if (g.epilogue < 0 || g.epilogue > VH_EPI_PATCH) return "gemm: unknown epilogue";
     if (g.epilogue == VH_EPI_PATCH && (!g.aux || g.aux_i <= 0)) return "gemm: EPI_PATCH needs pos-emb and patches/image";
     if (g.dtype != VH_DTYPE_BF16 && g.dtype != VH_DTYPE_FP16) return "gemm: dtype";
-    if (g.variant < 0 || g.variant > 5) return "gemm: variant";
+    if (g.variant < 0 || g.variant > 6) return "gemm: variant";
     if ((g.variant == 3 || g.variant == 4) && g.K % 32) return "gemm: K must be a multiple of 32";
     if (!g.a || !g.w || !g.bias || !g.out) return "gemm: null pointer";
     return nullptr;

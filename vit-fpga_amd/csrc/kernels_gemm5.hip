@@ -1,4 +1,5 @@
-// kernels_gemm5.hip — the ping-pong GEMM of the ViT hot path (gfx950), variant 5.
+// kernels_gemm5.hip — the ping-pong GEMM of the ViT hot path (gfx950), variants 5 (one tile per workgroup)
+// and 6 (persistent: one workgroup per CU walks the tiles and prefetches across tile boundaries).
 //
 // Same contract, operands, swizzled BK=64 LDS image and fused epilogues as kernels_gemm.hip; 256x256 tile,
 // 8 waves, two 64 KiB stages.  What changes is WHO uses the matrix pipe WHEN.
@@ -27,6 +28,11 @@
 //     L1 (4k+2 / 4k+3); a group's A half is read in its L0/L1 and refilled by the same group in its next L0.
 //   DMA of a tile is in flight for >= 4 phases (~2000 cycles) before it is needed; the waits are counted, the
 //   barriers raw, so later tiles' DMA stays in flight across them.
+//
+// Persistent mode: after the last phase of an output tile both stages are idle.  The workgroup issues the DMA
+// of the NEXT tile's K-tile 0 into stage 0, runs the epilogue through 8 KiB-per-wave slices of stage 1, then
+// issues K-tile 1 into stage 1: the next tile's first operands are already in LDS when its loop starts, and no
+// workgroup launch/drain sits between tiles.
 #include "gemm_epilogue.h"
 #include "vh_kernels.h"
 
@@ -41,8 +47,12 @@ __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
+__device__ __forceinline__ int xcd_remap(int bid, int n) {  // bijective on [0, n)
+    const int xcd = bid & 7, qd = n >> 3, rm = n & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+}
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool PERSIST>
 __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
@@ -55,11 +65,9 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
-    const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+    const int ntiles = tiles_m * tiles_n;
+    const int stride = PERSIST ? (int)gridDim.x : ntiles;
+    int t = xcd_remap(blockIdx.x, stride);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -68,15 +76,20 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
     // ---- DMA: this wave moves 4 x 1 KiB of its group's A half and 4 x 1 KiB of its group's W half -------
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
     const elem *gA[4], *gW[4];
+    int tile_m = 0, tile_n = 0;
+    auto setup_tile = [&](int tt) {
+        tile_m = tt / tiles_n;
+        tile_n = tt - tile_m * tiles_n;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = grp * 128 + (i * 4 + wn) * 8 + lr;
-        int ra = tile_m * BM + r, rw = tile_n * BN + r;
-        ra = ra < M ? ra : M - 1;
-        rw = rw < N ? rw : N - 1;
-        gA[i] = A + (int64_t)ra * K + lc * 8;
-        gW[i] = W + (int64_t)rw * K + lc * 8;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int r = grp * 128 + (i * 4 + wn) * 8 + lr;
+            int ra = tile_m * BM + r, rw = tile_n * BN + r;
+            ra = ra < M ? ra : M - 1;
+            rw = rw < N ? rw : N - 1;
+            gA[i] = A + (int64_t)ra * K + lc * 8;
+            gW[i] = W + (int64_t)rw * K + lc * 8;
+        }
+    };
     const int dma_off = grp * 16384 + wn * 1024;  // + i * 4096
     auto issue_a = [&](int kt) {
         char* dst = smem + (kt & 1) * STAGE_BYTES + dma_off;
@@ -100,101 +113,141 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
     const int xbase = grp * 16384;          // rows 128*grp ..
     const int wbase = W_OFF + wn * 8192;    // rows 64*wn ..
 
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    vec8 wf0[NI], wf1[NI], xf[MI];
-
     const int nk = K / BK;
 
-    // ---- prologue: tiles 0 and 1 ---------------------------------------------------------------------------------
+    // ---- prologue of the first tile: K-tiles 0 and 1 ------------------------------------------------------------
+    setup_tile(t);
     issue_w(0);
     issue_a(0);
     if (nk > 1) {
         issue_w(1);
         issue_a(1);
-        pp_wait_vmcnt<8>();
-    } else {
-        pp_wait_vmcnt<0>();
     }
-    pp_barrier();             // tile 0 visible
-    if (grp == 1) pp_barrier();  // G1 runs one phase behind
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* st = smem + (kt & 1) * STAGE_BYTES;
-        // ---- L0 ------------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            wf0[ni] = *(const vec8*)(st + wbase + ni * 2048 + off0);
-            wf1[ni] = *(const vec8*)(st + wbase + ni * 2048 + off1);
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off0);
-        if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-        pp_barrier();
-        // ---- C0 ------------------------------------------------------------------------------------------------
-        __builtin_amdgcn_s_setprio(1);
+    while (true) {
+        f32x4 acc[MI][NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf0[ni], xf[mi], acc[mi][ni]);
-        __builtin_amdgcn_s_setprio(0);
-        pp_barrier();
-        // ---- L1 ------------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off1);
-        if (kt + 2 < nk) {
-            issue_w(kt + 2);
-            pp_wait_vmcnt<8>();
-        } else if (kt + 1 < nk) {
-            pp_wait_vmcnt<4>();
-        } else {
-            pp_wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        pp_barrier();
-        // ---- C1 ------------------------------------------------------------------------------------------------
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf1[ni], xf[mi], acc[mi][ni]);
-        __builtin_amdgcn_s_setprio(0);
-        if (kt + 2 < nk) pp_wait_vmcnt<4>();
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        vec8 wf0[NI], wf1[NI], xf[MI];
+
+        if (nk > 1) pp_wait_vmcnt<8>();  // K-tile 0 landed (and any earlier stores), K-tile 1 may fly
         else pp_wait_vmcnt<0>();
-        pp_barrier();
-    }
-    if (grp == 0) pp_barrier();  // G0 waits for G1's last phase
+        pp_barrier();                 // K-tile 0 visible
+        if (grp == 1) pp_barrier();   // G1 runs one phase behind
 
-    gemm_epilogue<T, EPI, MI, NI>(acc, bias, outp, M, N, tile_m * BM + grp * 128, tile_n * BN + wn * 64, lane, aux, aux_i,
-                                  (tile_m + 1) * BM <= M && (tile_n + 1) * BN <= N, smem, wave);
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* st = smem + (kt & 1) * STAGE_BYTES;
+            // ---- L0 ------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                wf0[ni] = *(const vec8*)(st + wbase + ni * 2048 + off0);
+                wf1[ni] = *(const vec8*)(st + wbase + ni * 2048 + off1);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off0);
+            if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            pp_barrier();
+            // ---- C0 ------------------------------------------------------------------------------------------------
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf0[ni], xf[mi], acc[mi][ni]);
+            __builtin_amdgcn_s_setprio(0);
+            pp_barrier();
+            // ---- L1 ------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off1);
+            if (kt + 2 < nk) {
+                issue_w(kt + 2);
+                pp_wait_vmcnt<8>();
+            } else if (kt + 1 < nk) {
+                pp_wait_vmcnt<4>();
+            } else {
+                pp_wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            pp_barrier();
+            // ---- C1 ------------------------------------------------------------------------------------------------
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf1[ni], xf[mi], acc[mi][ni]);
+            __builtin_amdgcn_s_setprio(0);
+            if (kt + 2 < nk) pp_wait_vmcnt<4>();
+            else pp_wait_vmcnt<0>();
+            pp_barrier();
+        }
+        if (grp == 0) pp_barrier();  // G0 waits for G1's last phase: every LDS read of this tile is complete
+
+        // ---- tile boundary --------------------------------------------------------------------------------------
+        const int m_w = tile_m * BM + grp * 128, n_w = tile_n * BN + wn * 64;
+        const bool full = (tile_m + 1) * BM <= M && (tile_n + 1) * BN <= N;
+        const int t_next = t + stride;
+        const bool has_next = PERSIST && t_next < ntiles;
+        if (has_next) {
+            setup_tile(t_next);
+            issue_w(0);  // next tile's K-tile 0 -> stage 0 while the epilogue runs out of stage 1
+            issue_a(0);
+        }
+        gemm_epilogue<T, EPI, MI, NI, 4, false>(acc, bias, outp, M, N, m_w, n_w, lane, aux, aux_i, full,
+                                                smem + STAGE_BYTES, wave);
+        if (!has_next) break;
+        if (nk > 1) {
+            pp_barrier();  // every wave is done with its staging slice of stage 1
+            issue_w(1);
+            issue_a(1);
+        }
+        t = t_next;
+    }
 }
 
 template <typename T, int EPI>
-hipError_t launch_gemm_pingpong(const GemmArgs& g, hipStream_t s) {
+hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t s) {
     const int tiles_m = (int)((g.M + 255) / 256), tiles_n = (g.N + 255) / 256;
     constexpr size_t lds = 131072;
-    auto k = gemm_nt_pp_kernel<T, EPI>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        num_cu = prop.multiProcessorCount;
     }
-    hipLaunchKernelGGL(k, dim3(tiles_m * tiles_n), dim3(512), lds, s, (const typename T::elem*)g.a,
-                       (const typename T::elem*)g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n);
+    const int ntiles = tiles_m * tiles_n;
+    if (persistent) {
+        auto k = gemm_nt_pp_kernel<T, EPI, true>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k, dim3(ntiles < num_cu ? ntiles : num_cu), dim3(512), lds, s, (const typename T::elem*)g.a,
+                           (const typename T::elem*)g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n);
+    } else {
+        auto k = gemm_nt_pp_kernel<T, EPI, false>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k, dim3(ntiles), dim3(512), lds, s, (const typename T::elem*)g.a, (const typename T::elem*)g.w,
+                           g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n);
+    }
     return hipGetLastError();
 }
 
-#define VH_INST(T)                                                                               \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS>(const GemmArgs&, hipStream_t);       \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_GELU>(const GemmArgs&, hipStream_t);  \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_RESID>(const GemmArgs&, hipStream_t); \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_F32>(const GemmArgs&, hipStream_t);   \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_PATCH>(const GemmArgs&, hipStream_t);
+#define VH_INST(T)                                                                                     \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS>(const GemmArgs&, bool, hipStream_t);       \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_GELU>(const GemmArgs&, bool, hipStream_t);  \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_RESID>(const GemmArgs&, bool, hipStream_t); \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_F32>(const GemmArgs&, bool, hipStream_t);   \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_PATCH>(const GemmArgs&, bool, hipStream_t);
 VH_INST(BF16)
 VH_INST(FP16)
 
