@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection CSVs per kernel (average per launch).
+
+  python tools/pmc_summary.py gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 > profiles/rNN_pmc_summary.txt
+
+MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 4 SIMDs * 256 CUs) with GRBM_GUI_ACTIVE taken as the
+max over XCDs the way rocprofv3 reports it per dispatch (sum over 8 XCDs / 8).  FETCH_SIZE / WRITE_SIZE are KiB;
+per MI355X_MICROARCH.md §HBM, FETCH_SIZE reports exactly half the bytes of wide (16 B/lane) coalesced reads on
+gfx950, so the "HBM read (corrected)" column doubles it; WRITE_SIZE is taken as is.
+"""
+import csv
+import glob
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = name.replace("vh::", "").replace("void ", "")
+    return name[:64]
+
+
+def main():
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    dur = defaultdict(list)
+    for d in sys.argv[1:]:
+        for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+            seen = set()
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                c = r["Counter_Name"]
+                acc[k][c] += float(r["Counter_Value"])
+                cnt[k][c] += 1
+                key = (r["Dispatch_Id"], f)
+                if key not in seen:
+                    seen.add(key)
+                    dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print(f"{'kernel':66s} {'launches':>8s} {'avg us':>9s} {'MfmaUtil%':>9s} {'LDSconf%':>8s} {'HBM rd MB (x2 corr)':>20s} {'HBM wr MB':>10s} {'GB/s':>8s}")
+    rows = []
+    for k in acc:
+        a = {c: acc[k][c] / max(1, cnt[k][c]) for c in acc[k]}
+        n = max(cnt[k].values())
+        us = sum(dur[k]) / max(1, len(dur[k]))
+        gui = a.get("GRBM_GUI_ACTIVE", 0.0)
+        mf = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs by rocprofv3; MFMA busy is summed over all SIMDs
+        util = 100.0 * mf / (gui / 8 * 4 * 256) if gui else float("nan")
+        conf = 100.0 * a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_LDS_IDX_ACTIVE"] if a.get("SQ_LDS_IDX_ACTIVE") else float("nan")
+        rd = a.get("FETCH_SIZE", float("nan")) * 1024 * 2 / 1e6
+        wr = a.get("WRITE_SIZE", float("nan")) * 1024 / 1e6
+        bw = (rd + wr) / us * 1e3 / 1e3 if us else float("nan")
+        rows.append((sum(dur[k]), f"{k:66s} {n:8d} {us:9.1f} {util:9.1f} {conf:8.2f} {rd:20.1f} {wr:10.1f} {bw:8.0f}"))
+    for _, line in sorted(rows, reverse=True):
+        print(line)
+
+
+if __name__ == "__main__":
+    main()
