@@ -156,12 +156,31 @@ int vh_debug_set_layers(vh_ctx* ctx, int n_layers);
 #define VH_EPI_BIAS_RESID 2  /* out32[m,n] += acc + bias[n]        (fp32 residual stream)  */
 #define VH_EPI_BIAS_F32 3    /* out32[m,n]  = acc + bias[n]                                */
 #define VH_EPI_PATCH 4       /* out32[row(m),n] = acc + bias[n] + pos[tok(m),n]            */
+#define VH_EPI_LNFOLD 5      /* out16[m,n]  = rstd[m]*(acc - mean[m]*c[n]) + d[n]   (LayerNorm folded: bias = d, aux = c) */
+#define VH_EPI_LNFOLD_GELU 6 /* gelu of the above                                          */
+#define VH_EPI_RESID_LN 7    /* out32 += acc + bias; out16 = 16-bit copy; partials[N/64][M][2] = row (sum, sumsq) */
 /* out = epilogue(A[M,K] * W[N,K]^T); A and W hold `dtype` elements, K contiguous.
  * aux: EPI_PATCH -> pos-emb fp32 [tokens, N] with aux_i = patches per image.
- * variant: 0 = auto, 1 = 128x128 tile, 2 = 256x256 tile. */
+ * variant: 0 = auto, 1 = 128x128 tile, 2 = 256x256 two-stage, 5 = 256x256 ping-pong, 6 = persistent ping-pong. */
 int vh_op_gemm(const void* a16_dev, const void* w16_dev, const float* bias_dev, void* out_dev,
                int64_t M, int N, int K, int epilogue, const float* aux_dev, int aux_i,
                int dtype, int variant, void* stream);
+/* same with the operands of the LayerNorm-folding epilogues: stats [M][2] = (mean, rstd) for LNFOLD*,
+ * out16 [M,N] and partials [N/64][M][2] for RESID_LN (N must be a multiple of 256) */
+int vh_op_gemm_ex(const void* a16_dev, const void* w16_dev, const float* bias_dev, void* out_dev,
+                  int64_t M, int N, int K, int epilogue, const float* aux_dev, int aux_i,
+                  const float* stats_dev, void* out16_dev, float* partials_dev,
+                  int dtype, int variant, void* stream);
+/* row statistics helpers of the folded LayerNorm:
+ *   vh_op_rowstats_cast: x fp32 [rows, dim] -> x16 [rows, dim] (plain cast) and stats [rows][2] = (mean, rstd)
+ *   vh_op_finalize_stats: partials [nblk][rows][2] (sum, sumsq over 64-column blocks) -> stats [rows][2] */
+int vh_op_rowstats_cast(const float* x_dev, int64_t rows, int dim, float eps, void* x16_dev, float* stats_dev,
+                        int dtype, void* stream);
+int vh_op_finalize_stats(const float* partials_dev, int nblk, int64_t rows, int dim, float eps, float* stats_dev,
+                         void* stream);
+/* W'[n,k] = dtype(scale * gamma[k] * W[n,k]); c[n] = sum_k W'[n,k]; d[n] = scale * (sum_k beta[k] W[n,k] + b[n]) */
+int vh_op_fold_ln(const float* w_dev, const float* b_dev, const float* gamma_dev, const float* beta_dev, int rows,
+                  int dim, float scale, void* w16_dev, float* c_dev, float* d_dev, int dtype, void* stream);
 /* y16[r,:] = LN(x[r*row_stride : +dim]) * gamma + beta */
 int vh_op_layernorm(const float* x_dev, int64_t rows, int dim, int64_t row_stride,
                     const float* gamma_dev, const float* beta_dev, float eps, void* out16_dev,

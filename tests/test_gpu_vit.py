@@ -50,6 +50,22 @@ def test_logits_match_oracle(dt, name, batch):
     ctx.close()
 
 
+def test_vit_large_384_long_sequence_config():
+    # BASELINE.json config 4 as a parity case: ViT-L/16 at 384x384 (T = 577 tokens, 24 layers, fp16).
+    # One image keeps the CPU oracle at ~0.4 TFLOP; exercises the 152 KiB LDS-resident K/V path.
+    cfg = S.CONFIGS["vit_large_384"]
+    blob = S.make_blob(cfg, seed=0)
+    images = S.make_images(cfg, seed=1, batch=1)
+    ref = O.vit_forward(cfg, blob, images)
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=1)
+    ctx.load_weights(blob)
+    got = ctx.forward(images)
+    e = rel(got, ref)
+    print(f"\n[parity] vit_large_384 b1 fp16: logits {e:.3e}")
+    assert np.isfinite(got).all() and e <= 1.5e-3, e   # 24 layers: measured slightly above the 12-layer nets
+    ctx.close()
+
+
 @pytest.mark.parametrize("dt", [vithip.DTYPE_FP16, vithip.DTYPE_BF16])
 def test_logits_match_golden_fixtures(dt):
     for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))):
@@ -64,6 +80,25 @@ def test_logits_match_golden_fixtures(dt):
         print(f"\n[golden] {name} {NAME[dt]}: {e:.3e}")
         assert e <= TOL[dt], (name, e)
         ctx.close()
+
+
+def test_folded_layernorm_path_agrees_with_the_separate_layernorm_path(monkeypatch):
+    # ViT-B (dim % 256 == 0) runs with LayerNorm folded into the q|k|v and fc1 GEMMs; VH_LN_FOLD=0 selects the
+    # stand-alone LayerNorm kernel.  Both must sit within tolerance of the oracle and close to each other.
+    cfg = S.CONFIGS["vit_base"]
+    blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, 2)
+    ref = O.vit_forward(cfg, blob, images)
+    outs = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("VH_LN_FOLD", fold)
+        ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=2)
+        ctx.load_weights(blob)
+        outs[fold] = ctx.forward(images)
+        ctx.close()
+        assert rel(outs[fold], ref) <= 1e-3, (fold, rel(outs[fold], ref))
+    print(f"\n[fold] fp16 folded vs separate LN: {rel(outs['1'], outs['0']):.3e}")
+    assert not np.array_equal(outs["1"], outs["0"])   # they really are different code paths
+    assert rel(outs["1"], outs["0"]) <= 1e-3
 
 
 def test_layer_by_layer_against_oracle():

@@ -75,6 +75,9 @@ k(const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __res
     if (nk > 1 && DMA) { issue_w(1); issue_a(1); wv<8>(); } else wv<0>();
     __builtin_amdgcn_s_barrier();
     if (grp == 1) bar<DIAG>();
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    unsigned long long tp = __builtin_amdgcn_s_memtime();
+#define STAMP(i) if (DIAG & 32) { __builtin_amdgcn_sched_barrier(0); unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tp; tp = tn_; __builtin_amdgcn_sched_barrier(0); }
     for (int kt = 0; kt < nk; ++kt) {
         const char* st = smem + (kt & 1) * STAGE_BYTES;
         if (RD) {
@@ -83,9 +86,11 @@ k(const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __res
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off0);
         }
-        if (DMA && kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
+        if (DMA && !(DIAG & 64) && kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        STAMP(0)
         bar<DIAG>();
+        STAMP(4)
         if (MF) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -99,7 +104,9 @@ k(const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __res
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf0[ni]));
         }
+        STAMP(1)
         bar<DIAG>();
+        STAMP(4)
         if (RD) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off1);
@@ -108,13 +115,22 @@ k(const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __res
             if (kt + 2 < nk) { issue_w(kt + 2); wv<8>(); } else if (kt + 1 < nk) wv<4>(); else wv<0>();
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        STAMP(2)
         bar<DIAG>();
+        STAMP(4)
         if (MF) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[ni], xf[mi], acc[mi][ni], 0, 0, 0);
+                if ((DIAG & 64) && DMA && (mi & 1) == 0 && kt + 2 < nk) {
+                    const int i = mi >> 1;
+                    char* dst = smem + (kt & 1) * STAGE_BYTES + dma_off;
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gA[i] + (kt + 2) * BK),
+                                                     (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
         } else {
 #pragma unroll
@@ -122,8 +138,10 @@ k(const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __res
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf1[ni]));
         }
-        if (DMA) { if (kt + 2 < nk) wv<4>(); else wv<0>(); }
+        if (DMA) { if (kt + 2 < nk) { if (DIAG & 64) wv<8>(); else wv<4>(); } else wv<0>(); }
+        STAMP(3)
         bar<DIAG>();
+        STAMP(4)
     }
     if (grp == 0) bar<DIAG>();
     unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
@@ -142,6 +160,7 @@ k(const __bf16* __restrict__ A, const __bf16* __restrict__ W, const float* __res
     unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+    if (stamps && (DIAG & 32) && (threadIdx.x == 0 || threadIdx.x == 256)) { const int o = (threadIdx.x >> 8) * 5; for (int i = 0; i < 5; ++i) stamps[(size_t)gridDim.x * 4 + blockIdx.x * 10 + o + i] = ph[i]; }
     if (stamps && threadIdx.x == 0) { stamps[blockIdx.x * 4 + 0] = ts0; stamps[blockIdx.x * 4 + 1] = ts1; stamps[blockIdx.x * 4 + 2] = ts2; stamps[blockIdx.x * 4 + 3] = ts3; }
 }
 
@@ -187,6 +206,7 @@ int main() {
 #define R(D, label) t = run<D>(A, W, b, o, M, s.N, s.K, 20); printf("%s pp %-36s %8.1f us  %7.1f TF-equiv\n", s.name, label, t, fl / t / 1e6);
         R(0, "baseline")
         R(8, "no stores")
+        R(72, "no stores, A-DMA inside C1")
         R(9, "no DMA, no stores")
         R(13, "MFMA only")
         R(29, "MFMA only, no barriers")
@@ -208,6 +228,21 @@ int main() {
             // start-time histogram of the first 512 tiles, to see lockstep vs spread
             int hist[16] = {0}; for (int i = 0; i < nt; ++i) { unsigned long long d = (h[i*4+1] - t0) / 100; int bkt = (int)(d % 32) / 2; hist[bkt]++; }
             printf("%s mainloop-end time mod 32us histogram:", s.name); for (int i = 0; i < 16; ++i) printf(" %d", hist[i]); printf("\n");
+            hipFree(st);
+        }
+        {
+            const int tm = (M + 255) / 256, tn = (s.N + 255) / 256, nt = tm * tn;
+            unsigned long long* st; CK(hipMalloc(&st, (size_t)nt * (32 + 80)));
+            auto kern = k<40 + PPV>;  // stamps + no stores
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            hipLaunchKernelGGL(kern, dim3(nt), dim3(512), 131072, 0, A, W, b, o, M, s.N, s.K, tm, tn, st);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h((size_t)nt * 14);
+            CK(hipMemcpy(h.data(), st, (size_t)nt * 112, hipMemcpyDeviceToHost));
+            double sum[2][5] = {{0}};
+            for (int i = 0; i < nt; ++i) for (int g = 0; g < 2; ++g) for (int p = 0; p < 5; ++p) sum[g][p] += (double)h[(size_t)nt * 4 + i * 10 + g * 5 + p];
+            const double per = (double)nt * (s.K / 64);
+            for (int g = 0; g < 2; ++g) printf("%s phase cycles per K-tile, group %d: L0 %.0f  C0 %.0f  L1 %.0f  C1 %.0f  barrier-wait %.0f (4 barriers)\n", s.name, g, sum[g][0] / per, sum[g][1] / per, sum[g][2] / per, sum[g][3] / per, sum[g][4] / per);
             hipFree(st);
         }
         hipFree(A); hipFree(W); hipFree(o); hipFree(b);

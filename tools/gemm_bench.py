@@ -19,7 +19,7 @@ import vithip  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="2,3,4")
+    ap.add_argument("--variants", default="2,5,6")
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--config", default="vit_base")
     ap.add_argument("--dtype", default="bf16")

@@ -3,19 +3,47 @@
 // Accumulator layout (transposed-tile orientation, see kernels_gemm.hip): for the 16x16 tile
 // (mi, ni) of a wave, lane l holds rows m = m0 + 16*mi + (l & 15) and the 4 consecutive columns
 // n = n0 + 16*ni + 4*(l >> 4) + {0,1,2,3}.
+//
+// Epilogues (VH_EPI_* in include/vithip.h):
+//   BIAS / BIAS_GELU        out16 = [gelu](acc + bias)
+//   BIAS_RESID / BIAS_F32   out32 (+)= acc + bias
+//   PATCH                   out32[row(m)] = acc + bias + pos[tok(m)]
+//   LNFOLD / LNFOLD_GELU    out16 = [gelu]( rstd_m * (acc - mean_m * c_n) + d_n )
+//        LayerNorm folded into the GEMM: with W' = gamma o W the product LN(x) W^T equals
+//        rstd * (x W'^T - mean * c) + d,  c_n = sum_k W'_nk,  d_n = sum_k beta_k W_nk + b_n, so the
+//        GEMM runs on the RAW (16-bit rounded) residual rows and the per-row statistics enter here.
+//   RESID_LN                out32 += acc + bias; also writes the 16-bit copy of the updated rows and,
+//        per 64-column block, the row's (sum, sum of squares) — the producer side of LNFOLD.  Together
+//        they remove the stand-alone LayerNorm pass (read 310 MB + write 155 MB per LN at ViT-B b512).
 #pragma once
 
 #include "vh_common.h"
 
 namespace vh {
 
-// Phi(v) = 0.5 * erfc(-v / sqrt(2)) with erfc from Abramowitz & Stegun 7.1.26
-// (|abs error| <= 1.5e-7 on erf, i.e. below fp32 rounding of the surrounding arithmetic and four
-// orders of magnitude below the 16-bit rounding of the GELU output).  ~17 VALU ops per element
-// instead of ~45 for libm's erff: the fc1 epilogue evaluates 128 of these per lane per tile.
+struct EpiArgs {
+    const float* bias;   // [N]  (LNFOLD: d_n)
+    void* out;           // primary output
+    int M, N;
+    const float* aux;    // PATCH: pos-emb [tokens, N]; LNFOLD: c_n [N]
+    int aux_i;           // PATCH: patches per image
+    const float* stats;  // LNFOLD: [M][2] = (mean, rstd) of every row
+    void* out16;         // RESID_LN: 16-bit copy of the updated residual [M, N]
+    float* partials;     // RESID_LN: [N/64][M][2] = per-64-column (sum, sum of squares)
+};
+
+constexpr bool epi_is_16bit(int epi) {
+    return epi == VH_EPI_BIAS || epi == VH_EPI_BIAS_GELU || epi == VH_EPI_LNFOLD || epi == VH_EPI_LNFOLD_GELU;
+}
+constexpr bool epi_has_gelu(int epi) { return epi == VH_EPI_BIAS_GELU || epi == VH_EPI_LNFOLD_GELU; }
+constexpr bool epi_is_lnfold(int epi) { return epi == VH_EPI_LNFOLD || epi == VH_EPI_LNFOLD_GELU; }
+
+// exact-erf GELU: with x = |v|/sqrt(2), h = 0.5*erfc(x) = 0.5*poly(t)*t*exp(-x^2), t = 1/(1 + 0.3275911 x)
+// (Abramowitz & Stegun 7.1.26, |abs error| <= 1.5e-7 on erf: below fp32 rounding of the surrounding
+// arithmetic, four orders below the 16-bit rounding of the output);  gelu(v) = v*Phi(v) = max(v,0) - |v|*h
+// for both signs, no cancellation for v << 0.  13 VALU ops instead of ~45 for libm's erff: the fc1 epilogue
+// evaluates 128 of these per lane per tile.
 __device__ __forceinline__ float gelu_fast(float v) {
-    // with x = |v|/sqrt(2): h = 0.5*erfc(x) = 0.5*poly(t)*t*exp(-x^2), t = 1/(1 + 0.3275911 x);
-    // gelu(v) = v*Phi(v) = max(v,0) - |v|*h   (both signs; no cancellation for v << 0).  13 VALU ops.
     const float u = fabsf(v);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418882f, u, 1.0f));
     float p = fmaf(0.5307027145f, t, -0.7265760135f);
@@ -27,16 +55,50 @@ __device__ __forceinline__ float gelu_fast(float v) {
     return fmaf(-u, h, fmaxf(v, 0.f));
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15), result in every lane of the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0x128>(v);  // row_ror:8
+    v += dpp_mov<0x124>(v);  // row_ror:4
+    v += dpp_mov<0x122>(v);  // row_ror:2
+    v += dpp_mov<0x121>(v);  // row_ror:1
+    return v;
+}
+
+// value of one accumulator quad for the 16-bit epilogues
+template <int EPI>
+__device__ __forceinline__ f32x4 epi_value16(f32x4 acc, f32x4 bv, f32x4 cv, float mean_rstd, float rstd) {
+    f32x4 v;
+    if constexpr (epi_is_lnfold(EPI)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(rstd, acc[j], fmaf(-mean_rstd, cv[j], bv[j]));
+    } else {
+        v = acc + bv;
+    }
+    if constexpr (epi_has_gelu(EPI)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
+    }
+    return v;
+}
+
+// ---- direct (unstaged) epilogue: ragged-N tiles, the patch-row remap, small kernels -----------------------
 template <typename T, int EPI, int MI, int NI, bool GUARD>
-__device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], const float* __restrict__ bias,
-                                              void* __restrict__ outp, int M, int N, int m0, int n0,
-                                              const float* __restrict__ aux, int aux_i) {
+__device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m0, int n0) {
+    static_assert(EPI != VH_EPI_RESID_LN, "RESID_LN needs the staged path (N % tile == 0)");
     using elem = typename T::elem;
-    f32x4 bv[NI];
+    const int M = e.M, N = e.N;
+    f32x4 bv[NI], cv[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int n = n0 + ni * 16;
-        bv[ni] = (!GUARD || n < N) ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool ok = !GUARD || n < N;
+        bv[ni] = ok ? *(const f32x4*)(e.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (epi_is_lnfold(EPI)) cv[ni] = ok ? *(const f32x4*)(e.aux + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        else cv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -45,54 +107,59 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
         int64_t orow = m;
         const float* posrow = nullptr;
         if constexpr (EPI == VH_EPI_PATCH) {
-            const int img = m / aux_i, p = m - img * aux_i;
-            orow = (int64_t)img * (aux_i + 1) + 1 + p;
-            posrow = aux + (int64_t)(1 + p) * N;
+            const int img = m / e.aux_i, p = m - img * e.aux_i;
+            orow = (int64_t)img * (e.aux_i + 1) + 1 + p;
+            posrow = e.aux + (int64_t)(1 + p) * N;
+        }
+        float rstd = 0.f, mr = 0.f;
+        if constexpr (epi_is_lnfold(EPI)) {
+            const float2 st = *(const float2*)(e.stats + 2 * (int64_t)m);
+            rstd = st.y;
+            mr = st.x * st.y;
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n = n0 + ni * 16;
             if (GUARD && n >= N) continue;
-            f32x4 v = acc[mi][ni] + bv[ni];
-            if constexpr (EPI == VH_EPI_BIAS) {
-                *(typename T::vec4*)((elem*)outp + orow * N + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-            } else if constexpr (EPI == VH_EPI_BIAS_GELU) {
-                *(typename T::vec4*)((elem*)outp + orow * N + n) =
-                    pack4<T>(gelu_fast(v[0]), gelu_fast(v[1]), gelu_fast(v[2]), gelu_fast(v[3]));
-            } else if constexpr (EPI == VH_EPI_BIAS_RESID) {
-                f32x4* p = (f32x4*)((float*)outp + orow * N + n);
-                *p = *p + v;
-            } else if constexpr (EPI == VH_EPI_BIAS_F32) {
-                *(f32x4*)((float*)outp + orow * N + n) = v;
-            } else {  // VH_EPI_PATCH
-                *(f32x4*)((float*)outp + orow * N + n) = v + *(const f32x4*)(posrow + n);
+            if constexpr (epi_is_16bit(EPI)) {
+                const f32x4 v = epi_value16<EPI>(acc[mi][ni], bv[ni], cv[ni], mr, rstd);
+                *(typename T::vec4*)((elem*)e.out + orow * N + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+            } else {
+                const f32x4 v = acc[mi][ni] + bv[ni];
+                f32x4* p = (f32x4*)((float*)e.out + orow * N + n);
+                if constexpr (EPI == VH_EPI_BIAS_RESID) *p = *p + v;
+                else if constexpr (EPI == VH_EPI_BIAS_F32) *p = v;
+                else *p = v + *(const f32x4*)(posrow + n);  // VH_EPI_PATCH
             }
         }
     }
 }
 
-// ---- LDS-staged epilogue for full tiles -----------------------------------------------------------
+// ---- LDS-staged epilogue -------------------------------------------------------------------------------
 // The accumulator layout gives a lane 4 consecutive columns of 16 different rows, so a direct store
-// instruction touches 16 rows x 32 B (16-bit out) or x 64 B (fp32): partial lines, measured 3.5x
-// slower than full-line stores on the QKV shape.  Instead every wave transposes its own TM x 64 sub-tile
-// through a PRIVATE 16 KiB slice of the (now idle) operand stages and writes/reads HBM in whole
-// 128-B (16-bit) or 256-B (fp32) row segments, 16 B per lane.  Only one workgroup barrier is needed
-// (before the first LDS write: other waves may still be reading the last stage); write -> read-back is
-// wave-private.  `sw` = this wave's slice, m_w/n_w = first row/column of the wave's sub-tile.
-// SMI = 16-row blocks staged per pass for 16-bit output (slice = SMI*2 KiB per wave); fp32 stages SMI/2.
+// instruction touches 16 rows x 32 B (16-bit out) or x 64 B (fp32): partial lines, measured 3.5x slower than
+// full-line stores on the QKV shape.  Instead every wave transposes its own TM x 64 sub-tile through a PRIVATE
+// slice of the (now idle) operand stages and accesses HBM in whole 128-B (16-bit) or 256-B (fp32) row
+// segments, 16 B per lane.  Write -> read-back is wave-private (no barrier).  `sw` = this wave's slice,
+// m_w / n_w = first row / column of the wave's sub-tile; rows >= M are skipped (ragged last M-tile).
+// SMI = 16-row blocks staged per pass for 16-bit output (slice = SMI * 2 KiB per wave); fp32 stages SMI/2.
 template <typename T, int EPI, int MI, int NI, int SMI = MI>
-__device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI], const float* __restrict__ bias,
-                                                     void* __restrict__ outp, int N, int m_w, int n_w, int lane,
-                                                     char* sw) {
+__device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w,
+                                                     int lane, char* sw) {
     static_assert(NI == 4, "staged epilogue assumes a 64-column wave tile");
     static_assert(MI % SMI == 0 && SMI % 2 == 0, "slice must divide the wave tile");
     using elem = typename T::elem;
+    const int M = e.M, N = e.N;
     const int frow = lane & 15, fq = lane >> 4;
-    f32x4 bv[NI];
+    f32x4 bv[NI], cv[NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bv[ni] = *(const f32x4*)(bias + n_w + ni * 16 + fq * 4);
+    for (int ni = 0; ni < NI; ++ni) {
+        bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
+        if constexpr (epi_is_lnfold(EPI)) cv[ni] = *(const f32x4*)(e.aux + n_w + ni * 16 + fq * 4);
+        else cv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    if constexpr (EPI == VH_EPI_BIAS || EPI == VH_EPI_BIAS_GELU) {
+    if constexpr (epi_is_16bit(EPI)) {
         // rows of 64 x 16-bit = 128 B = 8 chunks of 16 B; chunk c of row r lives at chunk c ^ (r & 7)
         const int rr = lane >> 3, pc = lane & 7;
 #pragma unroll
@@ -100,12 +167,17 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
 #pragma unroll
             for (int mi = 0; mi < SMI; ++mi) {
                 const int r = mi * 16 + frow;
+                float rstd = 0.f, mr = 0.f;
+                if constexpr (epi_is_lnfold(EPI)) {
+                    int m = m_w + h * SMI * 16 + r;
+                    m = m < M ? m : M - 1;
+                    const float2 st = *(const float2*)(e.stats + 2 * (int64_t)m);
+                    rstd = st.y;
+                    mr = st.x * st.y;
+                }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    f32x4 v = acc[h * SMI + mi][ni] + bv[ni];
-                    if constexpr (EPI == VH_EPI_BIAS_GELU) {
-                        v[0] = gelu_fast(v[0]); v[1] = gelu_fast(v[1]); v[2] = gelu_fast(v[2]); v[3] = gelu_fast(v[3]);
-                    }
+                    const f32x4 v = epi_value16<EPI>(acc[h * SMI + mi][ni], bv[ni], cv[ni], mr, rstd);
                     const int c = ni * 2 + (fq >> 1);
                     *(typename T::vec4*)(sw + r * 128 + ((c ^ (r & 7)) << 4) + (fq & 1) * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
                 }
@@ -115,7 +187,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 const int r = i * 8 + rr;
                 const u32x4 v = *(const u32x4*)(sw + r * 128 + (pc << 4));
                 const int n = n_w + ((pc ^ (r & 7)) << 3);
-                *(u32x4*)((elem*)outp + (int64_t)(m_w + h * SMI * 16 + r) * N + n) = v;
+                const int m = m_w + h * SMI * 16 + r;
+                if (m < M) *(u32x4*)((elem*)e.out + (int64_t)m * N + n) = v;
             }
         }
     } else {
@@ -136,33 +209,45 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 const int r = i * 4 + rr;
                 f32x4 v = *(const f32x4*)(sw + r * 256 + (pc << 4));
                 const int n = n_w + ((pc ^ (r & 15)) << 2);
-                f32x4* p = (f32x4*)((float*)outp + (int64_t)(m_w + h * FMI * 16 + r) * N + n);
-                if constexpr (EPI == VH_EPI_BIAS_RESID) v = v + *p;
-                *p = v;
+                const int m = m_w + h * FMI * 16 + r;
+                const bool ok = m < M;
+                f32x4* p = (f32x4*)((float*)e.out + (int64_t)m * N + n);
+                if constexpr (EPI == VH_EPI_BIAS_RESID || EPI == VH_EPI_RESID_LN) {
+                    if (ok) v = v + *p;
+                }
+                if (ok) *p = v;
+                if constexpr (EPI == VH_EPI_RESID_LN) {
+                    // producer side of the folded LayerNorm: 16-bit copy + (sum, sumsq) of these 64 columns.
+                    // The 16 lanes of a DPP row hold one matrix row.
+                    if (ok) *(typename T::vec4*)((elem*)e.out16 + (int64_t)m * N + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+                    const float s2 = row16_sum(fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]));
+                    if (ok && pc == 0) *(float2*)(e.partials + 2 * ((int64_t)(n_w >> 6) * M + m)) = make_float2(s1, s2);
+                }
             }
         }
     }
 }
 
-// Full tiles (the common case) take the staged, unpredicated path; ragged tiles and the patch-row remap
-// store directly with per-element predicates.  `smem`/`wave_slice_bytes`: the kernel's dynamic LDS, which
-// must hold NW * SMI * 2 KiB from `smem` on.  With BARRIER it contains a workgroup barrier (needed when other
-// waves may still be reading the operand stages): call it from uniform control flow only.
+// Tiles whose 256/128 columns are all inside N take the staged path (rows are guarded inside); ragged-N tiles
+// and the patch-row remap store directly with per-element predicates.  `smem`: LDS holding NW * SMI * 2 KiB
+// from that address on.  With BARRIER it contains a workgroup barrier (needed when other waves may still be
+// reading the operand stages): call it from uniform control flow only.
 template <typename T, int EPI, int MI, int NI, int SMI = MI, bool BARRIER = true>
-__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const float* __restrict__ bias,
-                                              void* __restrict__ outp, int M, int N, int m_w, int n_w, int lane,
-                                              const float* __restrict__ aux, int aux_i, bool tile_is_full, char* smem,
-                                              int wave) {
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w, int lane,
+                                              bool n_full, bool m_full, char* smem, int wave) {
     if constexpr (EPI != VH_EPI_PATCH) {
-        if (tile_is_full) {
+        if (EPI == VH_EPI_RESID_LN || n_full) {
             if constexpr (BARRIER) __syncthreads();
-            gemm_epilogue_staged<T, EPI, MI, NI, SMI>(acc, bias, outp, N, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
+            gemm_epilogue_staged<T, EPI, MI, NI, SMI>(acc, e, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
             return;
         }
     }
-    const int m0 = m_w + (lane & 15), n0 = n_w + (lane >> 4) * 4;
-    if (tile_is_full) gemm_epilogue_impl<T, EPI, MI, NI, false>(acc, bias, outp, M, N, m0, n0, aux, aux_i);
-    else gemm_epilogue_impl<T, EPI, MI, NI, true>(acc, bias, outp, M, N, m0, n0, aux, aux_i);
+    if constexpr (EPI != VH_EPI_RESID_LN) {
+        const int m0 = m_w + (lane & 15), n0 = n_w + (lane >> 4) * 4;
+        if (n_full && m_full) gemm_epilogue_impl<T, EPI, MI, NI, false>(acc, e, m0, n0);
+        else gemm_epilogue_impl<T, EPI, MI, NI, true>(acc, e, m0, n0);
+    }
 }
 
 }  // namespace vh

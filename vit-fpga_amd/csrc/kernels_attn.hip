@@ -6,154 +6,218 @@
 // Head dimension is fixed at 64 (ViT-Ti/S/B/L/H all use 64).
 //
 // Design (CDNA4):
-//   * one workgroup per (image, head, query-slab); NW waves, each wave owns 32 query rows.
-//   * the whole K and V of the head are staged ONCE into LDS (T<=~600 keys: 2*T*128 B),
-//     K XOR-swizzled for conflict-free ds_read_b128 row reads, V swizzled for conflict-free
-//     ds_read_b64_tr_b16 transposed reads.
-//   * S^T = K Q^T with v_mfma_f32_32x32x16 (keys on the accumulator rows, the query on the
-//     lane): a query's scores live in ONE lane pair (l, l^32), so the softmax row max / sum
-//     are 15 in-register ops + one cross-half shuffle — a wavefront reduction, no LDS.
-//   * the S^T accumulator, converted to 16-bit in registers, IS the B operand of
-//     O^T = V^T P^T (same lane, k-order of the accumulator rows); V^T fragments come from the
-//     hardware transposing LDS read.  Scores/probabilities never touch LDS or HBM.
+//   * work item = (image, head, query slab of NW*32 rows); each wave owns 32 query rows.
+//   * the whole K and V of the head are staged into LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR
+//     round trip); K is XOR-swizzled for conflict-free ds_read_b128 row reads, V for conflict-free
+//     ds_read_b64_tr_b16 transposed reads — the DMA destination is linear, so both swizzles are applied to
+//     the lane's global SOURCE address.
+//   * persistent workgroups (when two K/V images fit in LDS): a workgroup walks its items and DMA-prefetches
+//     the next item's K/V into the other LDS buffer (and its Q fragments into registers) while it computes
+//     the current one.  The kernel is HBM-bound (620 MB per launch for ViT-B/16 at batch 512); the one-shot
+//     form (load, barrier, compute, store) only reached 55 % of the HBM rate because each workgroup's loads
+//     and math serialise and only two workgroups fit per CU.
+//   * S^T = K Q^T with v_mfma_f32_32x32x16 (keys on the accumulator rows, the query on the lane): a query's
+//     scores live in ONE lane pair (l, l^32), so the softmax row max / sum are 15 in-register ops + one
+//     cross-half shuffle — a wavefront reduction, no LDS.
+//   * the S^T accumulator, converted to 16-bit in registers, IS the B operand of O^T = V^T P^T (same lane,
+//     k-order of the accumulator rows); V^T fragments come from the hardware transposing LDS read.
+//     Scores/probabilities never touch LDS or HBM.
 //   * online softmax over 32-key tiles in the exp2 domain, fp32 statistics, keys >= T masked.
+#include <cstdlib>
+
 #include "vh_kernels.h"
 
 namespace vh {
 
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <typename T>
+// lanes l and l^32 hold the two halves of a query's row: combine them with one v_permlane32_swap
+// (a VALU exchange of the wave's halves) instead of a ds_bpermute round trip through the LDS crossbar
+// v_permlane32_swap vdst, src exchanges lanes 32-63 of vdst with lanes 0-31 of src IN PLACE, so the two
+// operands must be different registers: with one register it degenerates to a plain half swap.  The copy is
+// made opaque so the compiler cannot fold the operands back together.
+__device__ __forceinline__ void swap_halves(float v, float& lo_everywhere, float& hi_everywhere) {
+    // Whole exchange in one asm statement (hipcc 7.2 returned the same register for both results of
+    // __builtin_amdgcn_permlane32_swap here).  s_nop 1 = the 2 wait states of the "VALU write ->
+    // v_permlane read" hazard, which nobody pads inside inline asm; the trailing one covers the readers.
+    float a = v, b;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "=&v"(b));
+    lo_everywhere = a;  // {v[0..31], v[0..31]}
+    hi_everywhere = b;  // {v[32..63], v[32..63]}
+}
+__device__ __forceinline__ float cross_half_max(float v) {
+    float a, b;
+    swap_halves(v, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float cross_half_sum(float v) {
+    float a, b;
+    swap_halves(v, a, b);
+    return a + b;
+}
+
+template <typename T, bool PERSIST>
 __global__ void __launch_bounds__(512)
 attention_kernel(const typename T::elem* __restrict__ qkv, typename T::elem* __restrict__ out,
-                 int tokens, int heads, int slabs, int ntiles) {
+                 int tokens, int heads, int slabs, int ntiles, int nitems) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
     using vec4 = typename T::vec4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;
-    char* Vs = smem + ntiles * 4096;
-
-    const int bh = blockIdx.x / slabs, slab = blockIdx.x - bh * slabs;
-    const int b = bh / heads, h = bh - b * heads;
-    const int D = heads * 64;
-    const int64_t ld = 3 * (int64_t)D;
-    const elem* base = qkv + (int64_t)b * tokens * ld + h * 64;
-
-    // ---- stage K and V of this head into LDS (rows >= tokens replicate the last row) ------
-    const int nchunks = ntiles * 32 * 8;
-    for (int idx = threadIdx.x; idx < nchunks; idx += blockDim.x) {
-        const int row = idx >> 3, c = idx & 7;
-        const int rsrc = row < tokens ? row : tokens - 1;
-        const elem* src = base + rsrc * ld + c * 8;
-        const u32x4 kv = *(const u32x4*)(src + D);
-        const u32x4 vv = *(const u32x4*)(src + 2 * D);
-        *(u32x4*)(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
-        *(u32x4*)(Vs + row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4)) = vv;
-    }
+    const int kv_bytes = ntiles * 4096;      // one K (or V) image
+    const int buf_bytes = 2 * kv_bytes;      // K then V
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
     const int l31 = lane & 31, hl = lane >> 5;
-    const int q0 = (slab * nw + wave) * 32;
+    const int D = heads * 64;
+    const int64_t ld = 3 * (int64_t)D;
 
-    // ---- Q fragments: B operand of S^T = K Q^T, lane holds Q[q0 + l31][16*ks + 8*hl ..+7] ----
-    vec8 qf[4];
-    {
-        int qrow = q0 + l31;
+    // ---- DMA of one item's K and V: 1 KiB pieces = 8 rows x 128 B, lane -> (row, swizzled chunk) -------
+    const int lr = lane >> 3, pc = lane & 7;
+    const int ngroups = ntiles * 4;          // 8-row groups per matrix
+    auto issue_kv = [&](int item, int buf) {
+        const int bh = item / slabs;
+        const int b = bh / heads, h = bh - b * heads;
+        const elem* base = qkv + (int64_t)b * tokens * ld + h * 64;
+        char* kdst = smem + buf * buf_bytes;
+        for (int g = wave; g < ngroups; g += nw) {
+            const int row = g * 8 + lr;
+            const int rsrc = row < tokens ? row : tokens - 1;   // rows >= tokens replicate the last row
+            const elem* src = base + rsrc * ld;
+            const int ck = pc ^ ((row >> 1) & 7);
+            const int cv = pc ^ (((row >> 1) & 1) << 2);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + D + ck * 8),
+                                             (void __attribute__((address_space(3)))*)(kdst + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + 2 * D + cv * 8),
+                                             (void __attribute__((address_space(3)))*)(kdst + kv_bytes + g * 1024), 16, 0, 0);
+        }
+    };
+    auto load_q = [&](int item, vec8 (&qf)[4]) {
+        const int bh = item / slabs, slab = item - bh * slabs;
+        const int b = bh / heads, h = bh - b * heads;
+        int qrow = (slab * nw + wave) * 32 + l31;
         qrow = qrow < tokens ? qrow : tokens - 1;
-        const elem* qp = base + qrow * ld + 8 * hl;
+        const elem* qp = qkv + ((int64_t)b * tokens + qrow) * ld + h * 64 + 8 * hl;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const vec8*)(qp + 16 * ks);
-    }
-    __syncthreads();
-    if (q0 >= tokens) return;  // wave-uniform; after the only barrier
-
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m2 = -INFINITY;  // running row max, log2 domain
-    float lsum = 0.f;      // this lane's half of the row sum
+    };
 
     // per-lane LDS offsets
-    const int koff = l31 * 128;                 // + ((c ^ ((l31>>1)&7)) << 4)
+    const int koff = l31 * 128;
     const int kswz = (l31 >> 1) & 7;
-    const int g = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
-    // transposed V read: lane supplies &V[kbase + tq][dcol0 + 4*tp], dcol0 = 32*db + 16*(g&1)
-    const int vrow0 = 4 * (g >> 1) + tq;        // + 32*kt + 16*s (+8)
-    const int vcolb = (16 * (g & 1) + 4 * tp) * 2;  // byte offset inside the row, + 64*db
+    const int g4 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+    const int vrow0 = 4 * (g4 >> 1) + tq;             // + 32*kt + 16*s (+8)
+    const int vcolb = (16 * (g4 & 1) + 4 * tp) * 2;   // byte offset inside the row, + 64*db
 
-    for (int kt = 0; kt < ntiles; ++kt) {
-        // ---- S^T tile: 32 keys x 32 queries -------------------------------------------------
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        const char* kp = Ks + kt * 4096 + koff;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const vec8 kf = *(const vec8*)(kp + (((2 * ks + hl) ^ kswz) << 4));
-            s = T::mfma32(kf, qf[ks], s);
+    const int stride = PERSIST ? (int)gridDim.x : nitems;
+    int item = blockIdx.x;
+    int buf = 0;
+    vec8 qf[4], qn[4];
+    issue_kv(item, 0);
+    load_q(item, qf);
+
+    while (true) {
+        const int next = item + stride;
+        const bool has_next = PERSIST && next < nitems;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this item's K/V (and Q) have landed
+        __syncthreads();                                  // ... for every wave; previous item's reads are done
+        if (has_next) {
+            issue_kv(next, buf ^ 1);                      // flies under this item's math
+            load_q(next, qn);
         }
-        if (kt == ntiles - 1) {
+
+        const int bh = item / slabs, slab = item - bh * slabs;
+        const int b = bh / heads, h = bh - b * heads;
+        const int q0 = (slab * nw + wave) * 32;
+        const char* Ks = smem + buf * buf_bytes;
+        const char* Vs = Ks + kv_bytes;
+
+        if (q0 < tokens) {  // wave-uniform
+            f32x16 o0, o1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                if (key >= tokens) s[r] = -INFINITY;
+            for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+            float m2 = -INFINITY;  // running row max, log2 domain
+            float lsum = 0.f;      // this lane's half of the row sum
+
+            for (int kt = 0; kt < ntiles; ++kt) {
+                // ---- S^T tile: 32 keys x 32 queries ---------------------------------------------------
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                const char* kp = Ks + kt * 4096 + koff;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const vec8 kf = *(const vec8*)(kp + (((2 * ks + hl) ^ kswz) << 4));
+                    s = T::mfma32(kf, qf[ks], s);
+                }
+                if (kt == ntiles - 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                        if (key >= tokens) s[r] = -INFINITY;
+                    }
+                }
+                // ---- online softmax (row = query = lane pair) --------------------------------------------
+                float mx = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                mx = cross_half_max(mx);
+                const float mnew = fmaxf(m2, mx * kLog2e);
+                const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
+                m2 = mnew;
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], kLog2e, -mnew));
+                    psum += s[r];
+                }
+                lsum = fmaf(lsum, alpha, psum);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+                // ---- O^T += V^T P^T ----------------------------------------------------------------------
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    vec8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (elem)s[8 * ks + j];
+                    const int r_lo = kt * 32 + 16 * ks + vrow0, r_hi = r_lo + 8;
+                    const char* plo = Vs + r_lo * 128;
+                    const char* phi = Vs + r_hi * 128;
+                    const int xlo = ((r_lo >> 1) & 1) << 6, xhi = ((r_hi >> 1) & 1) << 6;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const int cb = vcolb + 64 * db;
+                        const vec4 a = T::tr_read(plo + (cb ^ xlo));
+                        const vec4 c = T::tr_read(phi + (cb ^ xhi));
+                        vec8 vf;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { vf[j] = a[j]; vf[4 + j] = c[j]; }
+                        if (db == 0) o0 = T::mfma32(vf, pf, o0); else o1 = T::mfma32(vf, pf, o1);
+                    }
+                }
+            }
+
+            // ---- normalise and store: lane holds O[q][32*db + 8*rg + 4*hl + 0..3] ------------------
+            const float ltot = cross_half_sum(lsum);
+            const float inv = 1.0f / ltot;
+            const int q = q0 + l31;
+            if (q < tokens) {
+                elem* op = out + ((int64_t)b * tokens + q) * D + h * 64 + 4 * hl;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    *(vec4*)(op + 8 * rg) = pack4<T>(o0[4 * rg] * inv, o0[4 * rg + 1] * inv, o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
+                    *(vec4*)(op + 32 + 8 * rg) = pack4<T>(o1[4 * rg] * inv, o1[4 * rg + 1] * inv, o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
+                }
             }
         }
-        // ---- online softmax (row = query = lane pair) ----------------------------------------
-        float mx = s[0];
+        if (!has_next) break;
+        item = next;
+        buf ^= 1;
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mnew = fmaxf(m2, mx * kLog2e);
-        const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
-        m2 = mnew;
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(s[r] * kLog2e - mnew);
-            psum += s[r];
-        }
-        lsum = lsum * alpha + psum;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-
-        // ---- O^T += V^T P^T ----------------------------------------------------------------------
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            vec8 pf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (elem)s[8 * ks + j];
-            const int r_lo = kt * 32 + 16 * ks + vrow0, r_hi = r_lo + 8;
-            const char* plo = Vs + r_lo * 128;
-            const char* phi = Vs + r_hi * 128;
-            const int xlo = ((r_lo >> 1) & 1) << 6, xhi = ((r_hi >> 1) & 1) << 6;
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int cb = vcolb + 64 * db;
-                const vec4 a = T::tr_read(plo + (cb ^ xlo));
-                const vec4 c = T::tr_read(phi + (cb ^ xhi));
-                vec8 vf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { vf[j] = a[j]; vf[4 + j] = c[j]; }
-                if (db == 0) o0 = T::mfma32(vf, pf, o0); else o1 = T::mfma32(vf, pf, o1);
-            }
-        }
-    }
-
-    // ---- normalise and store: lane holds O[q][32*db + 8*rg + 4*hl + 0..3] ------------------
-    const float ltot = lsum + __shfl_xor(lsum, 32);
-    const float inv = 1.0f / ltot;
-    const int q = q0 + l31;
-    if (q < tokens) {
-        elem* op = out + ((int64_t)b * tokens + q) * D + h * 64 + 4 * hl;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            *(vec4*)(op + 8 * rg) = pack4<T>(o0[4 * rg] * inv, o0[4 * rg + 1] * inv, o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
-            *(vec4*)(op + 32 + 8 * rg) = pack4<T>(o1[4 * rg] * inv, o1[4 * rg + 1] * inv, o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
-        }
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
     }
 }
 
@@ -165,17 +229,47 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     const int nqb = ntiles;
     const int slabs = (nqb + 7) / 8;
     const int nw = (nqb + slabs - 1) / slabs;
-    const size_t lds = attention_lds_bytes(tokens);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto k = attention_kernel<T>;
-    static size_t lds_max = 0;
-    if (lds > lds_max) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_max = lds;
+    const size_t one = attention_lds_bytes(tokens);
+    if (one > 160 * 1024) return hipErrorInvalidValue;
+    const int nitems = batch * heads * slabs;
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        num_cu = prop.multiProcessorCount;
     }
-    hipLaunchKernelGGL(k, dim3(batch * heads * slabs), dim3(nw * 64), lds, s,
-                       (const typename T::elem*)qkv, (typename T::elem*)out, tokens, heads, slabs, ntiles);
+    // persistent double-buffered form when two K/V images fit and there is more than one item per CU
+    // VH_ATTN_PERSIST=1 selects it; measured slower at T=197 (7 waves/CU leave the softmax latency-bound), so
+    // the default is the one-shot form with two workgroups per CU.
+    static int want_persist = -1;
+    if (want_persist < 0) { const char* e = getenv("VH_ATTN_PERSIST"); want_persist = e ? atoi(e) : 0; }
+    const bool persist = want_persist && 2 * one <= 160 * 1024 && nitems > num_cu;
+    if (persist) {
+        const size_t lds = 2 * one;
+        auto k = attention_kernel<T, true>;
+        static size_t lds_max = 0;
+        if (lds > lds_max) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_max = lds;
+        }
+        const int per_cu = (int)(160 * 1024 / lds);   // co-resident workgroups per CU by LDS
+        int grid = num_cu * (per_cu < 1 ? 1 : per_cu);
+        if (grid > nitems) grid = nitems;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(nw * 64), lds, s, (const typename T::elem*)qkv, (typename T::elem*)out,
+                           tokens, heads, slabs, ntiles, nitems);
+    } else {
+        auto k = attention_kernel<T, false>;
+        static size_t lds_max = 0;
+        if (one > lds_max) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)one);
+            if (e != hipSuccess) return e;
+            lds_max = one;
+        }
+        hipLaunchKernelGGL(k, dim3(nitems), dim3(nw * 64), one, s, (const typename T::elem*)qkv, (typename T::elem*)out,
+                           tokens, heads, slabs, ntiles, nitems);
+    }
     return hipGetLastError();
 }
 

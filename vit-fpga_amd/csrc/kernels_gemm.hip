@@ -33,7 +33,8 @@ template <typename T, int BM, int BN, int WM, int WN, int EPI>
 __global__ void __launch_bounds__(WM* WN * 64)
 gemm_nt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W,
                const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
-               const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n) {
+               const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
+               void* __restrict__ out16, float* __restrict__ partials) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
     constexpr int NW = WM * WN;
@@ -127,8 +128,9 @@ gemm_nt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     }
 
     // ---- epilogue: lane owns rows m = .. + (lane&15), 4 consecutive columns n = .. + 4*(lane>>4)
-    gemm_epilogue<T, EPI, MI, NI>(acc, bias, outp, M, N, tile_m * BM + wm * TM, tile_n * BN + wn * TN, lane, aux, aux_i,
-                                  (tile_m + 1) * BM <= M && (tile_n + 1) * BN <= N, smem, wave);
+    const EpiArgs e{bias, outp, M, N, aux, aux_i, stats, out16, partials};
+    gemm_epilogue<T, EPI, MI, NI>(acc, e, tile_m * BM + wm * TM, tile_n * BN + wn * TN, lane, (tile_n + 1) * BN <= N,
+                                  (tile_m + 1) * BM <= M, smem, wave);
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -145,12 +147,9 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
     }
     hipLaunchKernelGGL(k, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, s,
                        (const typename T::elem*)g.a, (const typename T::elem*)g.w, g.bias, g.out,
-                       (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n);
+                       (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n, g.stats, g.out16, g.partials);
     return hipGetLastError();
 }
-
-template <typename T, int EPI>
-hipError_t launch_gemm_pipelined(const GemmArgs& g, int variant, hipStream_t s);  // kernels_gemm3.hip
 
 template <typename T, int EPI>
 hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t s);  // kernels_gemm5.hip
@@ -158,7 +157,6 @@ hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t 
 template <typename T, int EPI>
 static hipError_t launch_tile(const GemmArgs& g, int variant, hipStream_t s) {
     if (variant == 5 || variant == 6) return launch_gemm_pingpong<T, EPI>(g, variant == 6, s);
-    if (variant >= 3) return launch_gemm_pipelined<T, EPI>(g, variant, s);
     if (variant == 2) return launch_one<T, 256, 256, 2, 4, EPI>(g, s);
     return launch_one<T, 128, 128, 2, 2, EPI>(g, s);
 }
@@ -171,6 +169,9 @@ static hipError_t launch_epi(const GemmArgs& g, int variant, hipStream_t s) {
     case VH_EPI_BIAS_RESID: return launch_tile<T, VH_EPI_BIAS_RESID>(g, variant, s);
     case VH_EPI_BIAS_F32: return launch_tile<T, VH_EPI_BIAS_F32>(g, variant, s);
     case VH_EPI_PATCH: return launch_tile<T, VH_EPI_PATCH>(g, variant, s);
+    case VH_EPI_LNFOLD: return launch_tile<T, VH_EPI_LNFOLD>(g, variant, s);
+    case VH_EPI_LNFOLD_GELU: return launch_tile<T, VH_EPI_LNFOLD_GELU>(g, variant, s);
+    case VH_EPI_RESID_LN: return launch_tile<T, VH_EPI_RESID_LN>(g, variant, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -185,11 +186,13 @@ const char* gemm_check(const GemmArgs& g) {
     if (g.K % 64) return "gemm: K must be a multiple of 64";
     if (g.N % 4) return "gemm: N must be a multiple of 4";
     if (g.M > 0x7fffffff) return "gemm: M too large";
-    if (g.epilogue < 0 || g.epilogue > VH_EPI_PATCH) return "gemm: unknown epilogue";
+    if (g.epilogue < 0 || g.epilogue > VH_EPI_RESID_LN) return "gemm: unknown epilogue";
+    if ((g.epilogue == VH_EPI_LNFOLD || g.epilogue == VH_EPI_LNFOLD_GELU) && (!g.stats || !g.aux)) return "gemm: LNFOLD needs stats and c (aux)";
+    if (g.epilogue == VH_EPI_RESID_LN && (!g.out16 || !g.partials || g.N % 256)) return "gemm: RESID_LN needs out16, partials and N % 256 == 0";
     if (g.epilogue == VH_EPI_PATCH && (!g.aux || g.aux_i <= 0)) return "gemm: EPI_PATCH needs pos-emb and patches/image";
     if (g.dtype != VH_DTYPE_BF16 && g.dtype != VH_DTYPE_FP16) return "gemm: dtype";
     if (g.variant < 0 || g.variant > 6) return "gemm: variant";
-    if ((g.variant == 3 || g.variant == 4) && g.K % 32) return "gemm: K must be a multiple of 32";
+    if (g.variant == 3 || g.variant == 4) return "gemm: variants 3/4 (BK=32 pipeline) were removed";
     if (!g.a || !g.w || !g.bias || !g.out) return "gemm: null pointer";
     return nullptr;
 }

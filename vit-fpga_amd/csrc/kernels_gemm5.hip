@@ -56,7 +56,8 @@ template <typename T, int EPI, bool PERSIST>
 __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
-                  const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n) {
+                  const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
+                  void* __restrict__ out16, float* __restrict__ partials) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
     constexpr int BM = 256, BN = 256, BK = 64;
@@ -186,7 +187,7 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
 
         // ---- tile boundary --------------------------------------------------------------------------------------
         const int m_w = tile_m * BM + grp * 128, n_w = tile_n * BN + wn * 64;
-        const bool full = (tile_m + 1) * BM <= M && (tile_n + 1) * BN <= N;
+        const bool m_full = (tile_m + 1) * BM <= M, n_full = (tile_n + 1) * BN <= N;
         const int t_next = t + stride;
         const bool has_next = PERSIST && t_next < ntiles;
         if (has_next) {
@@ -194,8 +195,8 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
             issue_w(0);  // next tile's K-tile 0 -> stage 0 while the epilogue runs out of stage 1
             issue_a(0);
         }
-        gemm_epilogue<T, EPI, MI, NI, 4, false>(acc, bias, outp, M, N, m_w, n_w, lane, aux, aux_i, full,
-                                                smem + STAGE_BYTES, wave);
+        const EpiArgs e{bias, outp, M, N, aux, aux_i, stats, out16, partials};
+        gemm_epilogue<T, EPI, MI, NI, 4, false>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);
         if (!has_next) break;
         if (nk > 1) {
             pp_barrier();  // every wave is done with its staging slice of stage 1
@@ -227,7 +228,8 @@ hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t 
             attr_done = true;
         }
         hipLaunchKernelGGL(k, dim3(ntiles < num_cu ? ntiles : num_cu), dim3(512), lds, s, (const typename T::elem*)g.a,
-                           (const typename T::elem*)g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n);
+                           (const typename T::elem*)g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n,
+                           g.stats, g.out16, g.partials);
     } else {
         auto k = gemm_nt_pp_kernel<T, EPI, false>;
         static bool attr_done = false;
@@ -237,7 +239,7 @@ hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t 
             attr_done = true;
         }
         hipLaunchKernelGGL(k, dim3(ntiles), dim3(512), lds, s, (const typename T::elem*)g.a, (const typename T::elem*)g.w,
-                           g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n);
+                           g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n, g.stats, g.out16, g.partials);
     }
     return hipGetLastError();
 }
@@ -247,7 +249,10 @@ hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t 
     template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_GELU>(const GemmArgs&, bool, hipStream_t);  \
     template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_RESID>(const GemmArgs&, bool, hipStream_t); \
     template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_F32>(const GemmArgs&, bool, hipStream_t);   \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_PATCH>(const GemmArgs&, bool, hipStream_t);
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_PATCH>(const GemmArgs&, bool, hipStream_t);       \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD>(const GemmArgs&, bool, hipStream_t);      \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD_GELU>(const GemmArgs&, bool, hipStream_t); \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_LN>(const GemmArgs&, bool, hipStream_t);
 VH_INST(BF16)
 VH_INST(FP16)
 

@@ -247,6 +247,119 @@ hipError_t launch_dense_layer(const float* w, const float* b, const float* x, fl
     return hipGetLastError();
 }
 
+// ---- folded LayerNorm: row statistics and weight folding -------------------------------------------------------
+// (the GEMM epilogues LNFOLD / RESID_LN of gemm_epilogue.h are the other half)
+
+// x fp32 [rows, dim] -> plain 16-bit cast + (mean, rstd) per row; one wave per row, like layernorm_kernel.
+// Used once per forward (first layer: its input comes from the patch embedding, not from a RESID_LN epilogue).
+template <typename T, int CH>
+__global__ void __launch_bounds__(256)
+rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float eps, typename T::elem* __restrict__ x16,
+                     float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = dim >> 2;
+    const f32x4* xr = (const f32x4*)(x + row * dim);
+    f32x4 v[CH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nchunk ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)dim;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; var += d * d; }
+            *(typename T::vec4*)(x16 + row * dim + 4 * c) = pack4<T>(v[i][0], v[i][1], v[i][2], v[i][3]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    if (lane == 0) *(float2*)(stats + 2 * row) = make_float2(mean, 1.0f / sqrtf(var / (float)dim + eps));
+}
+
+template <typename T>
+static hipError_t rowstats_t(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    auto o = (typename T::elem*)x16;
+    if (dim <= 256) hipLaunchKernelGGL((rowstats_cast_kernel<T, 1>), grid, block, 0, s, x, rows, dim, eps, o, stats);
+    else if (dim <= 512) hipLaunchKernelGGL((rowstats_cast_kernel<T, 2>), grid, block, 0, s, x, rows, dim, eps, o, stats);
+    else if (dim <= 768) hipLaunchKernelGGL((rowstats_cast_kernel<T, 3>), grid, block, 0, s, x, rows, dim, eps, o, stats);
+    else if (dim <= 1024) hipLaunchKernelGGL((rowstats_cast_kernel<T, 4>), grid, block, 0, s, x, rows, dim, eps, o, stats);
+    else if (dim <= 2048) hipLaunchKernelGGL((rowstats_cast_kernel<T, 8>), grid, block, 0, s, x, rows, dim, eps, o, stats);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_rowstats_cast(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, int dtype,
+                                hipStream_t s) {
+    if (rows <= 0 || dim <= 0 || (dim & 3)) return hipErrorInvalidValue;
+    return dtype == VH_DTYPE_BF16 ? rowstats_t<BF16>(x, rows, dim, eps, x16, stats, s)
+                                  : rowstats_t<FP16>(x, rows, dim, eps, x16, stats, s);
+}
+
+// partials [nblk][rows][2] = (sum, sum of squares) over 64-column blocks -> stats [rows][2] = (mean, rstd).
+// Fixed summation order (block 0, 1, ...) keeps the result independent of how the producing tiles were scheduled.
+__global__ void __launch_bounds__(256)
+finalize_stats_kernel(const float* __restrict__ partials, int nblk, int64_t rows, int dim, float eps, float* __restrict__ stats) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float2 p = *(const float2*)(partials + 2 * ((int64_t)b * rows + r));
+        s1 += p.x;
+        s2 += p.y;
+    }
+    const float mean = s1 / (float)dim;
+    const float var = fmaxf(s2 / (float)dim - mean * mean, 0.f);
+    *(float2*)(stats + 2 * r) = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+hipError_t launch_finalize_stats(const float* partials, int nblk, int64_t rows, int dim, float eps, float* stats, hipStream_t s) {
+    if (rows <= 0 || nblk <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, nblk, rows, dim, eps, stats);
+    return hipGetLastError();
+}
+
+// one wave per weight row n: W'[n,k] = T(scale*gamma[k]*W[n,k]); c[n] = sum_k float(W'[n,k]) (of the ROUNDED
+// values, so that mean*c cancels exactly what the MFMA accumulates); d[n] = scale*(sum_k beta[k]*W[n,k] + b[n])
+template <typename T>
+__global__ void __launch_bounds__(256)
+fold_ln_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+               const float* __restrict__ beta, int rows, int dim, float scale, typename T::elem* __restrict__ w16,
+               float* __restrict__ c, float* __restrict__ d) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= rows) return;
+    const float* wr = w + (int64_t)n * dim;
+    float cs = 0.f, ds = 0.f;
+    for (int k = lane; k < dim; k += 64) {
+        const float wv = wr[k];
+        const typename T::elem q = (typename T::elem)(scale * gamma[k] * wv);
+        w16[(int64_t)n * dim + k] = q;
+        cs += (float)q;
+        ds = fmaf(beta[k], wv, ds);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cs += __shfl_xor(cs, o); ds += __shfl_xor(ds, o); }
+    if (lane == 0) { c[n] = cs; d[n] = scale * (ds + b[n]); }
+}
+hipError_t launch_fold_ln(const float* w, const float* b, const float* gamma, const float* beta, int rows, int dim,
+                          float scale, void* w16, float* c, float* d, int dtype, hipStream_t s) {
+    if (rows <= 0 || dim <= 0) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == VH_DTYPE_BF16) hipLaunchKernelGGL(fold_ln_kernel<BF16>, grid, block, 0, s, w, b, gamma, beta, rows, dim, scale, (BF16::elem*)w16, c, d);
+    else hipLaunchKernelGGL(fold_ln_kernel<FP16>, grid, block, 0, s, w, b, gamma, beta, rows, dim, scale, (FP16::elem*)w16, c, d);
+    return hipGetLastError();
+}
+
 hipError_t init_kernel_attributes() { return hipSuccess; }
 
 }  // namespace vh

@@ -16,7 +16,10 @@ struct GemmArgs {
     const float* aux;   // EPI_PATCH: pos-emb [tokens, N]
     int aux_i;          // EPI_PATCH: patches per image
     int dtype;          // VH_DTYPE_*
-    int variant;        // 0 auto, 1 = 128x128, 2 = 256x256
+    int variant;        // 0 auto, 1 = 128x128, 2 = 256x256 two-stage, 5 = ping-pong, 6 = persistent ping-pong
+    const float* stats = nullptr;  // LNFOLD*: [M][2] (mean, rstd)
+    void* out16 = nullptr;         // RESID_LN: 16-bit copy of the updated rows
+    float* partials = nullptr;     // RESID_LN: [N/64][M][2]
 };
 
 // every launcher only enqueues on `stream`; returns hipSuccess or the launch error
@@ -43,6 +46,13 @@ hipError_t launch_pack_qkv(const float* qw, const float* qb, const float* kw, co
                            float* b32, int dtype, hipStream_t stream);
 hipError_t launch_permute_patch(const float* w_nchw, int dim, int channels, int patch, void* w16,
                                 int dtype, hipStream_t stream);
+// folded LayerNorm helpers
+hipError_t launch_rowstats_cast(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, int dtype,
+                                hipStream_t stream);
+hipError_t launch_finalize_stats(const float* partials, int nblk, int64_t rows, int dim, float eps, float* stats,
+                                 hipStream_t stream);
+hipError_t launch_fold_ln(const float* w, const float* b, const float* gamma, const float* beta, int rows, int dim,
+                          float scale, void* w16, float* c, float* d, int dtype, hipStream_t stream);
 // MLP mode: y = act(W x + b), W [n_out, n_in] fp32
 hipError_t launch_dense_layer(const float* w, const float* b, const float* x, float* y, int n_in,
                               int n_out, int n_vec, int activation, hipStream_t stream);

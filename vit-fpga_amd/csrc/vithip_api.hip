@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -102,9 +103,9 @@ const char* check_config(const vh_config& c) {
     return nullptr;
 }
 
-enum Stage { ST_IM2COL, ST_PATCH, ST_CLS, ST_LN, ST_QKV, ST_ATTN, ST_PROJ, ST_FC1, ST_FC2, ST_LNF, ST_HEAD, ST_COUNT };
+enum Stage { ST_IM2COL, ST_PATCH, ST_CLS, ST_LN, ST_QKV, ST_ATTN, ST_PROJ, ST_FC1, ST_FC2, ST_LNF, ST_HEAD, ST_LNSTATS, ST_COUNT };
 const char* kStageNames[ST_COUNT] = {"im2col", "patch_gemm", "cls_rows", "layernorm", "qkv_gemm", "attention",
-                                     "proj_gemm", "fc1_gemm", "fc2_gemm", "final_layernorm", "head_gemm"};
+                                     "proj_gemm", "fc1_gemm", "fc2_gemm", "final_layernorm", "head_gemm", "ln_stats"};
 
 }  // namespace
 
@@ -124,6 +125,11 @@ struct vh_ctx {
     void* head16 = nullptr;   // [C, D]
     std::vector<void*> wqkv16, wo16, w1_16, w2_16;
     float* bqkv = nullptr;    // [layers, 3D]
+    // LayerNorm folded into the q|k|v and fc1 GEMMs (dim and mlp_dim multiples of 256):
+    bool ln_fold = false;
+    float* fold_cd = nullptr; // per layer: cqkv[3D] dqkv[3D] c1[M] d1[M]
+    float* stats = nullptr;   // [B*T][2] (mean, rstd) of the current residual rows
+    float* partials = nullptr;// [D/64][B*T][2]
     // activations (sized for max_batch)
     char* arena = nullptr;
     float* x = nullptr;       // residual stream [B*T, D] fp32
@@ -180,10 +186,21 @@ int prepare_weights(vh_ctx* c) {
     HIPCHK(&c->err, launch_permute_patch(P + L.patch_w, D, f.channels, f.patch_size, c->wp16, f.dtype, s));
     for (int l = 0; l < f.layers; ++l) {
         const LayerOff& o = L.layer[l];
-        HIPCHK(&c->err, launch_pack_qkv(P + o.qw, P + o.qb, P + o.kw, P + o.kb, P + o.vw, P + o.vb, D, 0.125f,
-                                        c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, f.dtype, s));
+        if (c->ln_fold) {
+            // W' = gamma o W (q rows also carry the softmax scale), c = row sums of W', d = beta.W + b
+            float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
+            char* wq = (char*)c->wqkv16[l];
+            const size_t dd2 = (size_t)D * D * 2;
+            HIPCHK(&c->err, launch_fold_ln(P + o.qw, P + o.qb, P + o.ln1w, P + o.ln1b, D, D, 0.125f, wq, cd, cd + 3 * D, f.dtype, s));
+            HIPCHK(&c->err, launch_fold_ln(P + o.kw, P + o.kb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + dd2, cd + D, cd + 4 * D, f.dtype, s));
+            HIPCHK(&c->err, launch_fold_ln(P + o.vw, P + o.vb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + 2 * dd2, cd + 2 * D, cd + 5 * D, f.dtype, s));
+            HIPCHK(&c->err, launch_fold_ln(P + o.f1w, P + o.f1b, P + o.ln2w, P + o.ln2b, M, D, 1.0f, c->w1_16[l], cd + 6 * D, cd + 6 * D + M, f.dtype, s));
+        } else {
+            HIPCHK(&c->err, launch_pack_qkv(P + o.qw, P + o.qb, P + o.kw, P + o.kb, P + o.vw, P + o.vb, D, 0.125f,
+                                            c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, f.dtype, s));
+            HIPCHK(&c->err, launch_cast(P + o.f1w, c->w1_16[l], (int64_t)M * D, f.dtype, s));
+        }
         HIPCHK(&c->err, launch_cast(P + o.ow, c->wo16[l], (int64_t)D * D, f.dtype, s));
-        HIPCHK(&c->err, launch_cast(P + o.f1w, c->w1_16[l], (int64_t)M * D, f.dtype, s));
         HIPCHK(&c->err, launch_cast(P + o.f2w, c->w2_16[l], (int64_t)D * M, f.dtype, s));
     }
     HIPCHK(&c->err, launch_cast(P + L.headw, c->head16, (int64_t)f.classes * D, f.dtype, s));
@@ -220,6 +237,9 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     auto gemm = [&](const void* a, const void* w, const float* bias, void* out, int64_t Mr, int N, int K, int epi,
                     const float* aux, int aux_i) {
         GemmArgs g{a, w, bias, out, Mr, N, K, epi, aux, aux_i, f.dtype, 0};
+        g.stats = c->stats;        // read by LNFOLD*, ignored otherwise
+        g.out16 = c->xn16;         // written by RESID_LN
+        g.partials = c->partials;
         return launch_gemm(g, s);
     };
     // hip events around every launch of the stage selected by vh_set_stage_timing()
@@ -242,7 +262,43 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     HIPCHK(&c->err, launch_cls_rows(c->x, P + L.cls, P + L.pos, batch, T, D, s));
     if ((rc = mark(ST_CLS))) return rc;
     const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
-    for (int l = 0; l < nl; ++l) {
+    if (c->ln_fold && nl > 0) {
+        // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
+        HIPCHK(&c->err, launch_rowstats_cast(c->x, rows, D, f.ln_eps, c->xn16, c->stats, f.dtype, s));
+        if ((rc = mark(ST_LNSTATS))) return rc;
+    }
+    for (int l = 0; l < nl && c->ln_fold; ++l) {
+        const LayerOff& o = L.layer[l];
+        const float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
+        const int nblk = D / 64;
+        if ((rc = tmark(ST_QKV))) return rc;
+        HIPCHK(&c->err, gemm(c->xn16, c->wqkv16[l], cd + 3 * D, c->qkv16, rows, 3 * D, D, VH_EPI_LNFOLD, cd, 0));
+        if ((rc = tmark(ST_QKV))) return rc;
+        if ((rc = mark(ST_QKV))) return rc;
+        if ((rc = tmark(ST_ATTN))) return rc;
+        HIPCHK(&c->err, launch_attention(c->qkv16, batch, T, f.heads, c->att16, f.dtype, s));
+        if ((rc = tmark(ST_ATTN))) return rc;
+        if ((rc = mark(ST_ATTN))) return rc;
+        if ((rc = tmark(ST_PROJ))) return rc;
+        HIPCHK(&c->err, gemm(c->att16, c->wo16[l], P + o.ob, c->x, rows, D, D, VH_EPI_RESID_LN, nullptr, 0));
+        if ((rc = tmark(ST_PROJ))) return rc;
+        if ((rc = mark(ST_PROJ))) return rc;
+        HIPCHK(&c->err, launch_finalize_stats(c->partials, nblk, rows, D, f.ln_eps, c->stats, s));
+        if ((rc = mark(ST_LNSTATS))) return rc;
+        if ((rc = tmark(ST_FC1))) return rc;
+        HIPCHK(&c->err, gemm(c->xn16, c->w1_16[l], cd + 6 * D + M, c->h16, rows, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0));
+        if ((rc = tmark(ST_FC1))) return rc;
+        if ((rc = mark(ST_FC1))) return rc;
+        if ((rc = tmark(ST_FC2))) return rc;
+        HIPCHK(&c->err, gemm(c->h16, c->w2_16[l], P + o.f2b, c->x, rows, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0));
+        if ((rc = tmark(ST_FC2))) return rc;
+        if ((rc = mark(ST_FC2))) return rc;
+        if (l + 1 < nl) {
+            HIPCHK(&c->err, launch_finalize_stats(c->partials, nblk, rows, D, f.ln_eps, c->stats, s));
+            if ((rc = mark(ST_LNSTATS))) return rc;
+        }
+    }
+    for (int l = 0; l < nl && !c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
         if ((rc = tmark(ST_LN))) return rc;
         HIPCHK(&c->err, launch_layernorm(c->x, rows, D, D, P + o.ln1w, P + o.ln1b, f.ln_eps, c->xn16, f.dtype, s));
@@ -379,8 +435,18 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     for (int l = 0; l < cfg->layers; ++l) { o_qkv[l] = carve16(3 * D * D); o_o[l] = carve16(D * D); o_1[l] = carve16(M * D); o_2[l] = carve16(D * M); }
     const size_t o_bqkv = w16_bytes;
     w16_bytes += align_up((size_t)cfg->layers * 3 * D * 4, 256);
+    {
+        const char* e = getenv("VH_LN_FOLD");
+        // Opt-in (VH_LN_FOLD=1).  Measured on ViT-B/16 b512: the 24 stand-alone LayerNorm launches (1.94 ms, at the
+        // HBM roofline) disappear, but the RESID_LN / LNFOLD epilogues sit on every tile's critical path and cost
+        // 2.3 ms more than the plain ones -> 24.7 ms vs 24.4 ms per step.  Kept for shapes where it pays.
+        c->ln_fold = (cfg->dim % 256 == 0) && (cfg->mlp_dim % 256 == 0) && (e && e[0] == '1');
+    }
+    const size_t o_cd = w16_bytes;
+    w16_bytes += align_up((size_t)cfg->layers * (6 * D + 2 * M) * 4, 256);
     CK(hipMalloc((void**)&c->w16, w16_bytes));
     c->wp16 = c->w16 + o_wp; c->head16 = c->w16 + o_head; c->bqkv = (float*)(c->w16 + o_bqkv);
+    c->fold_cd = (float*)(c->w16 + o_cd);
     for (int l = 0; l < cfg->layers; ++l) {
         c->wqkv16.push_back(c->w16 + o_qkv[l]); c->wo16.push_back(c->w16 + o_o[l]);
         c->w1_16.push_back(c->w16 + o_1[l]); c->w2_16.push_back(c->w16 + o_2[l]);
@@ -391,11 +457,13 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     const size_t o_x = carve(rows * D * 4), o_xn = carve(rows * D * 2), o_qkvA = carve(rows * 3 * D * 2),
                  o_att = carve(rows * D * 2), o_h = carve(rows * M * 2), o_col = carve(B * L.NP * (size_t)L.KP * 2),
                  o_cls = carve(B * D * 2),
-                 o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4);
+                 o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4),
+                 o_st = carve(rows * 2 * 4), o_pt = carve((D / 64 + 1) * rows * 2 * 4);
     CK(hipMalloc((void**)&c->arena, a));
     c->x = (float*)(c->arena + o_x); c->xn16 = c->arena + o_xn; c->qkv16 = c->arena + o_qkvA; c->att16 = c->arena + o_att;
     c->h16 = c->arena + o_h; c->col16 = c->arena + o_col; c->clsn16 = c->arena + o_cls;
     c->in_dev = (float*)(c->arena + o_in); c->logits_dev = (float*)(c->arena + o_lg);
+    c->stats = (float*)(c->arena + o_st); c->partials = (float*)(c->arena + o_pt);
 #undef CK
     *out = c;
     return VH_OK;
@@ -671,6 +739,35 @@ int vh_op_gemm(const void* a, const void* w, const float* bias, void* out, int64
     GemmArgs g{a, w, bias, out, M, N, K, epi, aux, aux_i, dtype, variant};
     if (const char* why = gemm_check(g)) return fail(nullptr, VH_ERR_INVALID, "%s", why);
     OPCHK(launch_gemm(g, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_gemm_ex(const void* a, const void* w, const float* bias, void* out, int64_t M, int N, int K, int epi,
+                  const float* aux, int aux_i, const float* stats, void* out16, float* partials, int dtype, int variant,
+                  void* stream) {
+    GemmArgs g{a, w, bias, out, M, N, K, epi, aux, aux_i, dtype, variant};
+    g.stats = stats; g.out16 = out16; g.partials = partials;
+    if (const char* why = gemm_check(g)) return fail(nullptr, VH_ERR_INVALID, "%s", why);
+    OPCHK(launch_gemm(g, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_rowstats_cast(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, int dtype, void* stream) {
+    if (!x || !x16 || !stats || rows <= 0 || dim <= 0 || dim % 4 || dim > 2048) return fail(nullptr, VH_ERR_INVALID, "rowstats_cast: bad argument");
+    OPCHK(launch_rowstats_cast(x, rows, dim, eps, x16, stats, dtype, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_finalize_stats(const float* partials, int nblk, int64_t rows, int dim, float eps, float* stats, void* stream) {
+    if (!partials || !stats || nblk <= 0 || rows <= 0 || dim <= 0) return fail(nullptr, VH_ERR_INVALID, "finalize_stats: bad argument");
+    OPCHK(launch_finalize_stats(partials, nblk, rows, dim, eps, stats, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_fold_ln(const float* w, const float* b, const float* gamma, const float* beta, int rows, int dim, float scale,
+                  void* w16, float* c, float* d, int dtype, void* stream) {
+    if (!w || !b || !gamma || !beta || !w16 || !c || !d || rows <= 0 || dim <= 0) return fail(nullptr, VH_ERR_INVALID, "fold_ln: bad argument");
+    OPCHK(launch_fold_ln(w, b, gamma, beta, rows, dim, scale, w16, c, d, dtype, (hipStream_t)stream));
     OPCHK(hipStreamSynchronize((hipStream_t)stream));
     return VH_OK;
 }

@@ -15,11 +15,11 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "libvithip.so")
 
 DTYPE_BF16, DTYPE_FP16 = 0, 1
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH = range(5)
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH, EPI_LNFOLD, EPI_LNFOLD_GELU, EPI_RESID_LN = range(8)
 ACT_IDENTITY, ACT_RELU2, ACT_RELU, ACT_HARDTANH, ACT_GELU = range(5)
 
 STAGES = ["im2col", "patch_gemm", "cls_rows", "layernorm", "qkv_gemm", "attention", "proj_gemm",
-          "fc1_gemm", "fc2_gemm", "final_layernorm", "head_gemm"]
+          "fc1_gemm", "fc2_gemm", "final_layernorm", "head_gemm", "ln_stats"]
 
 
 class VhError(RuntimeError):
@@ -70,6 +70,10 @@ SYMBOLS = {
     "vh_debug_read": (_i, [_vp, _i, _vp, _sz]),
     "vh_debug_set_layers": (_i, [_vp, _i]),
     "vh_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "vh_op_gemm_ex": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "vh_op_rowstats_cast": (_i, [_vp, _i64, _i, _f, _vp, _vp, _i, _vp]),
+    "vh_op_finalize_stats": (_i, [_vp, _i, _i64, _i, _f, _vp, _vp]),
+    "vh_op_fold_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "vh_op_layernorm": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _f, _vp, _i, _vp]),
     "vh_op_attention": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "vh_op_im2col": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -311,6 +315,24 @@ class MlpContext:
 # ---- operator-level wrappers (device pointers in, nothing hidden) ------------------------------------
 def op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, dtype, aux_ptr=None, aux_i=0, variant=0):
     _check(lib().vh_op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, aux_ptr, aux_i, dtype, variant, None))
+
+
+def op_gemm_ex(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, dtype, aux_ptr=None, aux_i=0, stats_ptr=None,
+               out16_ptr=None, partials_ptr=None, variant=0):
+    _check(lib().vh_op_gemm_ex(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, aux_ptr, aux_i, stats_ptr, out16_ptr,
+                               partials_ptr, dtype, variant, None))
+
+
+def op_rowstats_cast(x_ptr, rows, dim, eps, x16_ptr, stats_ptr, dtype):
+    _check(lib().vh_op_rowstats_cast(x_ptr, rows, dim, eps, x16_ptr, stats_ptr, dtype, None))
+
+
+def op_finalize_stats(partials_ptr, nblk, rows, dim, eps, stats_ptr):
+    _check(lib().vh_op_finalize_stats(partials_ptr, nblk, rows, dim, eps, stats_ptr, None))
+
+
+def op_fold_ln(w_ptr, b_ptr, gamma_ptr, beta_ptr, rows, dim, scale, w16_ptr, c_ptr, d_ptr, dtype):
+    _check(lib().vh_op_fold_ln(w_ptr, b_ptr, gamma_ptr, beta_ptr, rows, dim, scale, w16_ptr, c_ptr, d_ptr, dtype, None))
 
 
 def bench_gemm(M, N, K, epilogue, dtype=DTYPE_BF16, variant=0, iters=20, device=0):
