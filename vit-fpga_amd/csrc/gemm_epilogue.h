@@ -188,7 +188,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 const u32x4 v = *(const u32x4*)(sw + r * 128 + (pc << 4));
                 const int n = n_w + ((pc ^ (r & 7)) << 3);
                 const int m = m_w + h * SMI * 16 + r;
-                if (m < M) *(u32x4*)((elem*)e.out + (int64_t)m * N + n) = v;
+                if (m < M) __builtin_nontemporal_store(v, (u32x4*)((elem*)e.out + (int64_t)m * N + n));
             }
         }
     } else {

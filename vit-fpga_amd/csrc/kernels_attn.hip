@@ -24,6 +24,7 @@
 //     Scores/probabilities never touch LDS or HBM.
 //   * online softmax over 32-key tiles in the exp2 domain, fp32 statistics, keys >= T masked.
 #include <cstdlib>
+#include <type_traits>
 
 #include "vh_kernels.h"
 
@@ -141,18 +142,25 @@ attention_kernel(const typename T::elem* __restrict__ qkv, typename T::elem* __r
             float m2 = -INFINITY;  // running row max, log2 domain
             float lsum = 0.f;      // this lane's half of the row sum
 
-            for (int kt = 0; kt < ntiles; ++kt) {
+            // lane-constant LDS addresses: K row reads (4 swizzled chunks) and the transposed V reads
+            // (two bases: the 32-column block db flips bit 6 of the swizzled byte offset)
+            const char* kbase = Ks + koff;
+            int kofs[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kofs[ks] = ((2 * ks + hl) ^ kswz) << 4;
+            const int vx = ((vrow0 >> 1) & 1) << 6;   // same for rows +8, +16, +32*kt
+            const char* vb0 = Vs + vrow0 * 128 + (vcolb ^ vx);
+            const char* vb1 = Vs + vrow0 * 128 + ((vcolb + 64) ^ vx);
+
+            auto tile = [&](int kt, auto masked) {
                 // ---- S^T tile: 32 keys x 32 queries ---------------------------------------------------
                 f32x16 s;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = 0.f;
-                const char* kp = Ks + kt * 4096 + koff;
+                const char* kp = kbase + kt * 4096;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const vec8 kf = *(const vec8*)(kp + (((2 * ks + hl) ^ kswz) << 4));
-                    s = T::mfma32(kf, qf[ks], s);
-                }
-                if (kt == ntiles - 1) {
+                for (int ks = 0; ks < 4; ++ks) s = T::mfma32(*(const vec8*)(kp + kofs[ks]), qf[ks], s);
+                if constexpr (decltype(masked)::value) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
@@ -165,40 +173,47 @@ attention_kernel(const typename T::elem* __restrict__ qkv, typename T::elem* __r
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
                 mx = cross_half_max(mx);
                 const float mnew = fmaxf(m2, mx * kLog2e);
-                const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
-                m2 = mnew;
+                // rescale the running sums only when some row's maximum moved (exact: alpha == 1 otherwise)
+                if (__builtin_amdgcn_ballot_w64(mnew != m2)) {
+                    const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
+                    lsum *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                    m2 = mnew;
+                }
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], kLog2e, -mnew));
                     psum += s[r];
                 }
-                lsum = fmaf(lsum, alpha, psum);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-
+                lsum += psum;
                 // ---- O^T += V^T P^T ----------------------------------------------------------------------
+                const char* v0 = vb0 + kt * 4096;
+                const char* v1 = vb1 + kt * 4096;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     vec8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (elem)s[8 * ks + j];
-                    const int r_lo = kt * 32 + 16 * ks + vrow0, r_hi = r_lo + 8;
-                    const char* plo = Vs + r_lo * 128;
-                    const char* phi = Vs + r_hi * 128;
-                    const int xlo = ((r_lo >> 1) & 1) << 6, xhi = ((r_hi >> 1) & 1) << 6;
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        const int cb = vcolb + 64 * db;
-                        const vec4 a = T::tr_read(plo + (cb ^ xlo));
-                        const vec4 c = T::tr_read(phi + (cb ^ xhi));
+                    {
+                        const vec4 a = T::tr_read(v0 + ks * 2048), c = T::tr_read(v0 + ks * 2048 + 1024);
                         vec8 vf;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { vf[j] = a[j]; vf[4 + j] = c[j]; }
-                        if (db == 0) o0 = T::mfma32(vf, pf, o0); else o1 = T::mfma32(vf, pf, o1);
+                        o0 = T::mfma32(vf, pf, o0);
+                    }
+                    {
+                        const vec4 a = T::tr_read(v1 + ks * 2048), c = T::tr_read(v1 + ks * 2048 + 1024);
+                        vec8 vf;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { vf[j] = a[j]; vf[4 + j] = c[j]; }
+                        o1 = T::mfma32(vf, pf, o1);
                     }
                 }
-            }
+            };
+            for (int kt = 0; kt + 1 < ntiles; ++kt) tile(kt, std::false_type{});
+            tile(ntiles - 1, std::true_type{});   // only the last tile can hold keys >= tokens
 
             // ---- normalise and store: lane holds O[q][32*db + 8*rg + 4*hl + 0..3] ------------------
             const float ltot = cross_half_sum(lsum);
