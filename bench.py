@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even with one rank")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time table to stderr")
+    ap.add_argument("--streams", type=int, default=0, help="split every forward into N concurrent parts (0 = library default, 1)")
     args = ap.parse_args()
 
     import vh_dist
@@ -64,6 +65,9 @@ def main():
     dt = vithip.DTYPE_BF16 if args.dtype == "bf16" else vithip.DTYPE_FP16
     B = args.batch
     ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B, device=local_rank)
+    if args.streams > 0:
+        ctx.set_streams(args.streams)
+    streams = ctx.get_streams()
 
     # ---- weights: rank 0 generates, RCCL broadcast of the canonical fp32 blob ---------------------
     if use_dist:
@@ -127,7 +131,11 @@ def main():
         ips = total_images / elapsed
         flops_img = S.flops_per_image(cfg)
         T = S.tokens(cfg)
-        fc1_flops = 2.0 * B * T * cfg["mlp_dim"] * cfg["dim"]
+        fc1_flops = 2.0 * (B / streams) * T * cfg["mlp_dim"] * cfg["dim"]  # every launch handles one part of the batch
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_e_fc1_traffic.json")
+        if args.config == "vit_base" and B == 512 and streams == 1 and args.dtype == "bf16" and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]  # PMC passes of this command, see that file
         achieved = fc1_flops / (fc1_avg_ms * 1e-3) / 1e12 if fc1_avg_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
         out = {
@@ -144,7 +152,7 @@ def main():
             "forward_mfma_frac": round(ips / world * flops_img / (peak * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_pp_kernel<bias+GELU> 256x256x64 ping-pong (fc1)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "concurrent_parts": streams,
                          "flop_per_launch": fc1_flops, "avg_launch_ms": round(fc1_avg_ms, 5),
                          "min_launch_ms": round(fc1_min_ms, 5), "launches_timed": fc1_n},
         }

@@ -124,6 +124,14 @@ int vh_synchronize(vh_ctx* ctx);
  * def/defines.h:11-12) */
 int vh_fill_input_seeded(vh_ctx* ctx, uint64_t seed, int batch, float* in_nhwc_dev);
 
+/* Concurrency inside one forward: the batch is split into `n` contiguous parts (1..4, default 1, environment
+ * VH_STREAMS) that are enqueued on separate streams and joined at the end of every forward.  Images are
+ * independent, so the logits are bit-identical for every n; with n = 2 the HBM-bound stages and the partly
+ * filled last tile round of one half overlap the MFMA-bound stages of the other (+5 % images/s at ViT-B b512).
+ * Off by default: two kernels then share the device, so a per-launch duration no longer measures one kernel. */
+int vh_set_streams(vh_ctx* ctx, int n);
+int vh_get_streams(const vh_ctx* ctx, int* n);
+
 /* observability: replaces forward_performance / get_forward_performance
  * (netFPGA.cpp:262-264,280-284,603-611).  us = host wall time of the last vh_forward*,
  * kernel_ms = device time between hip events around the last forward's kernels. */

@@ -133,6 +133,25 @@ def test_deterministic_and_batch_independent():
     ctx.close()
 
 
+def test_concurrent_parts_give_bit_identical_logits():
+    # vh_set_streams(n): the batch runs as n contiguous parts on n streams; images are independent, so every n
+    # (and uneven splits: 5 images in 2, 3, 4 parts) must reproduce the single-stream logits bit for bit
+    cfg = S.CONFIGS["vit_tiny"]
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_BF16, max_batch=5)
+    ctx.load_weights(S.make_blob(cfg, 0))
+    images = S.make_images(cfg, 1, 5)
+    ctx.set_streams(1)
+    ref = ctx.forward(images)
+    for n in (2, 3, 4):
+        ctx.set_streams(n)
+        assert ctx.get_streams() == n
+        assert np.array_equal(ctx.forward(images), ref), n
+        assert np.array_equal(ctx.forward(images[:1]), ref[:1]), n   # fewer images than parts
+    with pytest.raises(vithip.VhError):
+        ctx.set_streams(9)
+    ctx.close()
+
+
 def test_device_resident_path_equals_host_path():
     cfg = S.CONFIGS["vit_mini"]
     batch = 4

@@ -114,6 +114,11 @@ struct vh_ctx {
     int device;
     Layout L;
     hipStream_t stream = nullptr;
+    // optional extra streams: the batch is split into `nstreams` contiguous parts that run concurrently
+    static constexpr int kMaxStreams = 4;
+    hipStream_t xstream[kMaxStreams - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams - 1] = {nullptr, nullptr, nullptr};
+    int nstreams = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool weights_ready = false;
     int run_layers = -1;
@@ -219,13 +224,24 @@ int check_blob_header(vh_ctx* c, const BlobHeader& h) {
 }
 
 // the launch sequence of ONE forward; `ev` (optional) receives an event after every stage
-int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::vector<std::pair<int, hipEvent_t>>* ev) {
+// `img0`: first image of this part inside the activation arena (a batch can be split into parts that run on
+// different streams: rows of different images never interact), `s`: the stream to enqueue on.
+int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::vector<std::pair<int, hipEvent_t>>* ev,
+                    hipStream_t s, int img0) {
     const vh_config& f = c->cfg;
     const Layout& L = c->L;
     const int D = f.dim, M = f.mlp_dim, T = L.T;
     const int64_t rows = (int64_t)batch * T;
-    hipStream_t s = c->stream;
     const float* P = c->params;
+    // this part's slices of the arena
+    const size_t r0 = (size_t)img0 * T, esz = 2;
+    float* const x = c->x + r0 * D;
+    char* const xn16 = (char*)c->xn16 + r0 * D * esz;
+    char* const qkv16 = (char*)c->qkv16 + r0 * 3 * D * esz;
+    char* const att16 = (char*)c->att16 + r0 * D * esz;
+    char* const h16 = (char*)c->h16 + r0 * M * esz;
+    char* const col16 = (char*)c->col16 + (size_t)img0 * L.NP * L.KP * esz;
+    char* const clsn16 = (char*)c->clsn16 + (size_t)img0 * D * esz;
     auto mark = [&](int stage) -> int {
         if (!ev) return VH_OK;
         hipEvent_t e;
@@ -238,7 +254,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
                     const float* aux, int aux_i) {
         GemmArgs g{a, w, bias, out, Mr, N, K, epi, aux, aux_i, f.dtype, 0};
         g.stats = c->stats;        // read by LNFOLD*, ignored otherwise
-        g.out16 = c->xn16;         // written by RESID_LN
+        g.out16 = xn16;            // written by RESID_LN
         g.partials = c->partials;
         return launch_gemm(g, s);
     };
@@ -255,16 +271,16 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     };
     int rc;
     if ((rc = mark(-1))) return rc;
-    HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, c->col16, f.dtype, s));
+    HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, col16, f.dtype, s));
     if ((rc = mark(ST_IM2COL))) return rc;
-    HIPCHK(&c->err, gemm(c->col16, c->wp16, P + L.patch_b, c->x, (int64_t)batch * L.NP, D, L.KP, VH_EPI_PATCH, P + L.pos, L.NP));
+    HIPCHK(&c->err, gemm(col16, c->wp16, P + L.patch_b, x, (int64_t)batch * L.NP, D, L.KP, VH_EPI_PATCH, P + L.pos, L.NP));
     if ((rc = mark(ST_PATCH))) return rc;
-    HIPCHK(&c->err, launch_cls_rows(c->x, P + L.cls, P + L.pos, batch, T, D, s));
+    HIPCHK(&c->err, launch_cls_rows(x, P + L.cls, P + L.pos, batch, T, D, s));
     if ((rc = mark(ST_CLS))) return rc;
     const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
     if (c->ln_fold && nl > 0) {
         // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
-        HIPCHK(&c->err, launch_rowstats_cast(c->x, rows, D, f.ln_eps, c->xn16, c->stats, f.dtype, s));
+        HIPCHK(&c->err, launch_rowstats_cast(x, rows, D, f.ln_eps, xn16, c->stats, f.dtype, s));
         if ((rc = mark(ST_LNSTATS))) return rc;
     }
     for (int l = 0; l < nl && c->ln_fold; ++l) {
@@ -272,25 +288,25 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         const float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
         const int nblk = D / 64;
         if ((rc = tmark(ST_QKV))) return rc;
-        HIPCHK(&c->err, gemm(c->xn16, c->wqkv16[l], cd + 3 * D, c->qkv16, rows, 3 * D, D, VH_EPI_LNFOLD, cd, 0));
+        HIPCHK(&c->err, gemm(xn16, c->wqkv16[l], cd + 3 * D, qkv16, rows, 3 * D, D, VH_EPI_LNFOLD, cd, 0));
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(c->qkv16, batch, T, f.heads, c->att16, f.dtype, s));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, f.dtype, s));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
-        HIPCHK(&c->err, gemm(c->att16, c->wo16[l], P + o.ob, c->x, rows, D, D, VH_EPI_RESID_LN, nullptr, 0));
+        HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows, D, D, VH_EPI_RESID_LN, nullptr, 0));
         if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
         HIPCHK(&c->err, launch_finalize_stats(c->partials, nblk, rows, D, f.ln_eps, c->stats, s));
         if ((rc = mark(ST_LNSTATS))) return rc;
         if ((rc = tmark(ST_FC1))) return rc;
-        HIPCHK(&c->err, gemm(c->xn16, c->w1_16[l], cd + 6 * D + M, c->h16, rows, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0));
+        HIPCHK(&c->err, gemm(xn16, c->w1_16[l], cd + 6 * D + M, h16, rows, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0));
         if ((rc = tmark(ST_FC1))) return rc;
         if ((rc = mark(ST_FC1))) return rc;
         if ((rc = tmark(ST_FC2))) return rc;
-        HIPCHK(&c->err, gemm(c->h16, c->w2_16[l], P + o.f2b, c->x, rows, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0));
+        HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, x, rows, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0));
         if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
         if (l + 1 < nl) {
@@ -301,37 +317,37 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     for (int l = 0; l < nl && !c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
         if ((rc = tmark(ST_LN))) return rc;
-        HIPCHK(&c->err, launch_layernorm(c->x, rows, D, D, P + o.ln1w, P + o.ln1b, f.ln_eps, c->xn16, f.dtype, s));
+        HIPCHK(&c->err, launch_layernorm(x, rows, D, D, P + o.ln1w, P + o.ln1b, f.ln_eps, xn16, f.dtype, s));
         if ((rc = tmark(ST_LN))) return rc;
         if ((rc = mark(ST_LN))) return rc;
         if ((rc = tmark(ST_QKV))) return rc;
-        HIPCHK(&c->err, gemm(c->xn16, c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, c->qkv16, rows, 3 * D, D, VH_EPI_BIAS, nullptr, 0));
+        HIPCHK(&c->err, gemm(xn16, c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, qkv16, rows, 3 * D, D, VH_EPI_BIAS, nullptr, 0));
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(c->qkv16, batch, T, f.heads, c->att16, f.dtype, s));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, f.dtype, s));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
-        HIPCHK(&c->err, gemm(c->att16, c->wo16[l], P + o.ob, c->x, rows, D, D, VH_EPI_BIAS_RESID, nullptr, 0));
+        HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows, D, D, VH_EPI_BIAS_RESID, nullptr, 0));
         if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
         if ((rc = tmark(ST_LN))) return rc;
-        HIPCHK(&c->err, launch_layernorm(c->x, rows, D, D, P + o.ln2w, P + o.ln2b, f.ln_eps, c->xn16, f.dtype, s));
+        HIPCHK(&c->err, launch_layernorm(x, rows, D, D, P + o.ln2w, P + o.ln2b, f.ln_eps, xn16, f.dtype, s));
         if ((rc = tmark(ST_LN))) return rc;
         if ((rc = mark(ST_LN))) return rc;
         if ((rc = tmark(ST_FC1))) return rc;
-        HIPCHK(&c->err, gemm(c->xn16, c->w1_16[l], P + o.f1b, c->h16, rows, M, D, VH_EPI_BIAS_GELU, nullptr, 0));
+        HIPCHK(&c->err, gemm(xn16, c->w1_16[l], P + o.f1b, h16, rows, M, D, VH_EPI_BIAS_GELU, nullptr, 0));
         if ((rc = tmark(ST_FC1))) return rc;
         if ((rc = mark(ST_FC1))) return rc;
         if ((rc = tmark(ST_FC2))) return rc;
-        HIPCHK(&c->err, gemm(c->h16, c->w2_16[l], P + o.f2b, c->x, rows, D, M, VH_EPI_BIAS_RESID, nullptr, 0));
+        HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, x, rows, D, M, VH_EPI_BIAS_RESID, nullptr, 0));
         if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
     }
-    HIPCHK(&c->err, launch_layernorm(c->x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, c->clsn16, f.dtype, s));
+    HIPCHK(&c->err, launch_layernorm(x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn16, f.dtype, s));
     if ((rc = mark(ST_LNF))) return rc;
-    HIPCHK(&c->err, gemm(c->clsn16, c->head16, P + L.headb, logits, batch, f.classes, D, VH_EPI_BIAS_F32, nullptr, 0));
+    HIPCHK(&c->err, gemm(clsn16, c->head16, P + L.headb, logits, batch, f.classes, D, VH_EPI_BIAS_F32, nullptr, 0));
     if ((rc = mark(ST_HEAD))) return rc;
     c->last_batch = batch;
     return VH_OK;
@@ -422,6 +438,17 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     auto bail = [&](int code) { vh_destroy(c); return code; };
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, VH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(VH_ERR_HIP); } } while (0)
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < vh_ctx::kMaxStreams - 1; ++i) {
+        CK(hipStreamCreateWithFlags(&c->xstream[i], hipStreamNonBlocking));
+        CK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
+    {
+        const char* e = getenv("VH_STREAMS");
+        c->nstreams = e ? atoi(e) : 1;
+        if (c->nstreams < 1) c->nstreams = 1;
+        if (c->nstreams > vh_ctx::kMaxStreams) c->nstreams = vh_ctx::kMaxStreams;
+    }
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
     // canonical blob
@@ -479,6 +506,11 @@ int vh_destroy(vh_ctx* c) {
     for (hipEvent_t e : c->tev) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    for (int i = 0; i < vh_ctx::kMaxStreams - 1; ++i) {
+        if (c->xstream[i]) { hipStreamSynchronize(c->xstream[i]); hipStreamDestroy(c->xstream[i]); }
+        if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return VH_OK;
@@ -584,8 +616,31 @@ int vh_forward_device_async(vh_ctx* c, const float* in, int batch, float* logits
     HIPCHK(&c->err, hipSetDevice(c->device));
     c->tev_used = 0;
     HIPCHK(&c->err, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < steps; ++i)
-        if ((rc = enqueue_forward(c, in, batch, logits, nullptr))) return rc;
+    const size_t img_floats = (size_t)c->cfg.image_size * c->cfg.image_size * c->cfg.channels;
+    for (int i = 0; i < steps; ++i) {
+        const int parts = c->ln_fold ? 1 : (batch < c->nstreams ? batch : c->nstreams);
+        if (parts > 1) {
+            // contiguous parts of the batch on different streams: the HBM-bound stages and the partly filled
+            // tail rounds of one part overlap the MFMA-bound stages of another (identical results: images
+            // are independent and every per-row reduction has a fixed order)
+            HIPCHK(&c->err, hipEventRecord(c->ev_fork, c->stream));
+            int b0 = 0;
+            for (int p = 0; p < parts; ++p) {
+                const int nb = batch / parts + (p < batch % parts ? 1 : 0);
+                hipStream_t st = p == 0 ? c->stream : c->xstream[p - 1];
+                if (p) HIPCHK(&c->err, hipStreamWaitEvent(st, c->ev_fork, 0));
+                if ((rc = enqueue_forward(c, in + (size_t)b0 * img_floats, nb, logits + (size_t)b0 * c->cfg.classes, nullptr, st, b0))) return rc;
+                if (p) {
+                    HIPCHK(&c->err, hipEventRecord(c->ev_join[p - 1], st));
+                    HIPCHK(&c->err, hipStreamWaitEvent(c->stream, c->ev_join[p - 1], 0));
+                }
+                b0 += nb;
+            }
+            c->last_batch = batch;
+        } else if ((rc = enqueue_forward(c, in, batch, logits, nullptr, c->stream, 0))) {
+            return rc;
+        }
+    }
     HIPCHK(&c->err, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return VH_OK;
@@ -659,7 +714,7 @@ int vh_profile_forward(vh_ctx* c, const float* in, int batch, float* logits, dou
     if (!stage_ms || n_slots < 2 * ST_COUNT) return fail(&c->err, VH_ERR_INVALID, "need %d stage slots (ms then launch counts)", 2 * ST_COUNT);
     HIPCHK(&c->err, hipSetDevice(c->device));
     std::vector<std::pair<int, hipEvent_t>> ev;
-    rc = enqueue_forward(c, in, batch, logits, &ev);
+    rc = enqueue_forward(c, in, batch, logits, &ev, c->stream, 0);
     if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) rc = fail(&c->err, VH_ERR_HIP, "sync: %s", hipGetErrorString(e)); }
     for (int i = 0; i < 2 * ST_COUNT; ++i) stage_ms[i] = 0.0;
     if (!rc)
@@ -672,6 +727,21 @@ int vh_profile_forward(vh_ctx* c, const float* in, int batch, float* logits, dou
     for (auto& p : ev) hipEventDestroy(p.second);
     if (n_written) *n_written = ST_COUNT;
     return rc;
+}
+
+int vh_set_streams(vh_ctx* c, int n) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    if (n < 1 || n > vh_ctx::kMaxStreams) return fail(&c->err, VH_ERR_INVALID, "streams must be 1..%d", vh_ctx::kMaxStreams);
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    c->nstreams = n;
+    return VH_OK;
+}
+
+int vh_get_streams(const vh_ctx* c, int* n) {
+    if (!c || !n) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *n = c->ln_fold ? 1 : c->nstreams;
+    return VH_OK;
 }
 
 int vh_set_stage_timing(vh_ctx* c, int stage) {

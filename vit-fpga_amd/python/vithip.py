@@ -65,6 +65,8 @@ SYMBOLS = {
     "vh_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double)]),
     "vh_profile_forward": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_double), _i, _pi]),
     "vh_stage_name": (C.c_char_p, [_i]),
+    "vh_set_streams": (_i, [_vp, _i]),
+    "vh_get_streams": (_i, [_vp, _pi]),
     "vh_set_stage_timing": (_i, [_vp, _i]),
     "vh_get_stage_timing": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _pi]),
     "vh_debug_read": (_i, [_vp, _i, _vp, _sz]),
@@ -256,6 +258,14 @@ class VitContext:
         nw = C.c_int(0)
         _check(lib().vh_profile_forward(self.h, in_ptr, batch, out_ptr, arr, 2 * n, C.byref(nw)), self.h)
         return {STAGES[i]: (arr[i], int(arr[n + i])) for i in range(n)}
+
+    def set_streams(self, n):
+        _check(lib().vh_set_streams(self.h, n), self.h)
+
+    def get_streams(self):
+        n = C.c_int(0)
+        _check(lib().vh_get_streams(self.h, C.byref(n)), self.h)
+        return n.value
 
     def set_stage_timing(self, stage_name):
         _check(lib().vh_set_stage_timing(self.h, STAGES.index(stage_name) if stage_name else -1), self.h)
