@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even with one rank")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time table to stderr")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also measure the PCIe-inclusive rate through the pinned submit/collect ring (extra object, never `value`)")
     ap.add_argument("--streams", type=int, default=0, help="split every forward into N concurrent parts (0 = library default, 1)")
     args = ap.parse_args()
 
@@ -122,6 +124,10 @@ def main():
     if not np.isfinite(logits).all():
         raise SystemExit("non-finite logits")
 
+    host_path = None
+    if args.host_path:
+        host_path = host_path_rate(ctx, cfg, B, args.steps, np, S)
+
     stages = None
     if args.stages and rank == 0:
         stages = ctx.profile_forward(din.ptr, B, dout.ptr)
@@ -158,6 +164,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        if host_path:
+            out["host_path"] = host_path
         if stages:
             tot = sum(v[0] for v in stages.values())
             for k, (ms, n) in stages.items():
@@ -169,6 +177,37 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_path_rate(ctx, cfg, B, steps, np, S):
+    """PCIe-inclusive rate: images start in (pinned) HOST memory and logits end in host memory, through the
+    vh_ring_* pipeline (3 slots: upload of batch i+1 and download of batch i-1 overlap the forward of batch i)."""
+    slots = 3
+    ctx.ring_create(slots, B)
+    sample = S.make_images(cfg, 7, min(B, 8))
+    for _ in range(slots):          # fill every slot's pinned staging buffer once (a producer writes there in place)
+        buf = ctx.ring_input(B)
+        for i in range(0, B, len(sample)):
+            buf[i:i + len(sample)] = sample[:min(len(sample), B - i)]
+        ctx.ring_submit(None, B)
+    for _ in range(slots):
+        ctx.ring_collect()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    inflight = 0
+    for _ in range(steps):
+        if inflight == slots:
+            ctx.ring_collect(); inflight -= 1
+        ctx.ring_submit(None, B); inflight += 1
+    while inflight:
+        last = ctx.ring_collect(); inflight -= 1
+    dt = time.perf_counter() - t0
+    if not np.isfinite(last).all():
+        raise SystemExit("non-finite logits (host path)")
+    in_gb = B * cfg["image_size"] ** 2 * cfg["channels"] * 4 / 1e9
+    return {"value": round(B * steps / dt, 2), "unit": "images/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "slots": slots, "h2d_GB_per_step": round(in_gb, 4),
+            "note": "fp32 NHWC images from pinned host memory -> logits in host memory, vh_ring_submit/collect"}
 
 
 def cpu_baseline(cfg, target_seconds):

@@ -37,6 +37,8 @@ extern "C" {
 #define VH_ERR_STATE 3       /* call order violated (e.g. forward before weights)     */
 #define VH_ERR_UNSUPPORTED 4 /* valid request that this build does not implement      */
 #define VH_ERR_NO_DEVICE 5   /* no gfx950 device visible                              */
+#define VH_ERR_RING_FULL 6   /* vh_ring_submit: every slot is in flight (reference: "PILA LLENA") */
+#define VH_ERR_RING_EMPTY 7  /* vh_ring_collect: nothing in flight (reference: "PILA VACIA")      */
 
 /* arithmetic type of the dense contractions (MFMA operand type; accumulation is fp32) */
 #define VH_DTYPE_BF16 0
@@ -123,6 +125,23 @@ int vh_synchronize(vh_ctx* ctx);
 /* uniform[-1,1) synthetic images written straight into HBM (value range of the reference,
  * def/defines.h:11-12) */
 int vh_fill_input_seeded(vh_ctx* ctx, uint64_t seed, int batch, float* in_nhwc_dev);
+
+/* ---- pipelined host path ------------------------------------------------------------------------------------
+ * A ring of in-flight batches, modelled on the reference's only asynchronous pattern: the 24-slot ring of
+ * filter_image / get_filtered_image (netFPGA.cpp:292-365, ring state :47-56).  vh_ring_submit enqueues
+ * H2D copy -> forward -> D2H copy of one batch into the next free slot and returns at once; vh_ring_collect waits
+ * for the OLDEST submitted batch and copies its logits out (FIFO).  Copies run on their own streams from pinned
+ * staging buffers, so the upload of batch i+1 and the download of batch i-1 overlap the forward of batch i and the
+ * host-pointer rate approaches the device-resident rate.  Full ring / empty ring are returned as
+ * VH_ERR_RING_FULL / VH_ERR_RING_EMPTY (the reference prints and drops the frame, :330-333, :358-361).
+ *   vh_ring_input gives the pinned staging buffer of the slot the next submit will use: fill it in place and
+ *   submit with in_nhwc_host = NULL to skip the extra host copy. */
+int vh_ring_create(vh_ctx* ctx, int slots, int batch_per_slot);
+int vh_ring_destroy(vh_ctx* ctx);
+int vh_ring_free_slots(const vh_ctx* ctx, int* n);
+int vh_ring_input(vh_ctx* ctx, float** pinned_in_nhwc);
+int vh_ring_submit(vh_ctx* ctx, const float* in_nhwc_host, int batch);
+int vh_ring_collect(vh_ctx* ctx, float* logits_host, int* batch);
 
 /* Concurrency inside one forward: the batch is split into `n` contiguous parts (1..4, default 1, environment
  * VH_STREAMS) that are enqueued on separate streams and joined at the end of every forward.  Images are

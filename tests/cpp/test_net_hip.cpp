@@ -136,6 +136,18 @@ static void gpu_checks()
     for (size_t i = 0; i < want.size(); ++i) { mx = std::fmax(mx, std::fabs(want[i])); err = std::fmax(err, std::fabs(got2[i] - want[i])); }
     CHECK(err / mx <= 1e-3f);
     CHECK(seeded.get_forward_performance() > 0 && seeded.last_kernel_ms() > 0.0);
+
+    // ---- pipelined submit/collect: FIFO, same logits as launch_forward, reference-style full/empty reports ----
+    seeded.set_pipeline(2, B);
+    CHECK(seeded.collect_forward().empty());                 // "PILA VACIA"
+    const std::vector<float> one(img.begin(), img.begin() + 64 * 64 * 3);
+    CHECK(seeded.submit_forward(img) && seeded.submit_forward(one));
+    CHECK(!seeded.submit_forward(one));                      // "PILA LLENA": two slots, both in flight
+    const std::vector<float> r0 = seeded.collect_forward(), r1 = seeded.collect_forward();
+    CHECK(r0 == got2);
+    CHECK(r1.size() == 40 && std::equal(r1.begin(), r1.end(), got2.begin()));
+    CHECK(seeded.collect_forward().empty());
+    CHECK(seeded.launch_forward(img) == got2);               // the synchronous call still works next to the pipeline
 }
 
 int main(int argc, char **argv)

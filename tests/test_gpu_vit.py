@@ -152,6 +152,52 @@ def test_concurrent_parts_give_bit_identical_logits():
     ctx.close()
 
 
+def test_ring_pipelined_submit_collect_is_fifo_and_equals_forward():
+    # the in-flight ring (reference pattern: filter_image / get_filtered_image, netFPGA.cpp:292-365): results come
+    # back in submission order, bit-identical to the synchronous forward, for ragged batch sizes, with both ways
+    # of handing over the input (caller buffer / the slot's pinned buffer filled in place)
+    cfg = S.CONFIGS["vit_tiny"]
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=4)
+    ctx.load_weights(S.make_blob(cfg, 2))
+    sizes = [4, 1, 3, 4, 2, 4, 1]
+    batches = [S.make_images(cfg, 10 + i, n) for i, n in enumerate(sizes)]
+    refs = [ctx.forward(b) for b in batches]
+    with pytest.raises(vithip.VhError):
+        ctx.ring_submit(batches[0])          # no ring yet
+    ctx.ring_create(3, 4)
+    assert ctx.ring_free_slots() == 3
+    with pytest.raises(vithip.VhError) as e:
+        ctx.ring_collect()                   # "PILA VACIA"
+    assert e.value.code == 7
+    got = []
+    for i, b in enumerate(batches):
+        if ctx.ring_free_slots() == 0:
+            with pytest.raises(vithip.VhError) as e:
+                ctx.ring_submit(b)           # "PILA LLENA"
+            assert e.value.code == 6
+            got.append(ctx.ring_collect())
+        if i % 2:
+            ctx.ring_input(len(b))[...] = b  # fill the pinned slot in place
+            ctx.ring_submit(None, len(b))
+        else:
+            ctx.ring_submit(b)
+    while ctx.ring_free_slots() < 3:
+        got.append(ctx.ring_collect())
+    assert len(got) == len(refs)
+    for g, r in zip(got, refs):
+        assert g.shape == r.shape and np.array_equal(g, r)
+    with pytest.raises(vithip.VhError):
+        ctx.ring_submit(S.make_images(cfg, 1, 5))   # larger than a slot
+    # the synchronous path still works with a ring present, and with concurrent parts under the ring
+    ctx.set_streams(2)
+    ctx.ring_submit(batches[0])
+    ctx.ring_submit(batches[2])
+    assert np.array_equal(ctx.ring_collect(), refs[0])
+    assert np.array_equal(ctx.forward(batches[1]), refs[1])
+    assert np.array_equal(ctx.ring_collect(), refs[2])
+    ctx.close()
+
+
 def test_device_resident_path_equals_host_path():
     cfg = S.CONFIGS["vit_mini"]
     batch = 4

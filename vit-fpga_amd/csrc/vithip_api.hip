@@ -149,6 +149,15 @@ struct vh_ctx {
     int64_t last_us = 0;
     bool timed = false;
     int last_batch = 0;
+    // pipelined host path (vh_ring_*): slots of pinned host staging + device buffers, copies on their own streams
+    struct RingSlot {
+        float *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+        hipEvent_t in_done = nullptr, fwd_done = nullptr, out_done = nullptr;
+        int batch = 0;
+    };
+    std::vector<RingSlot> ring;
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    int ring_batch = 0, ring_wr = 0, ring_rd = 0, ring_used = 0;
     // optional per-launch timing of ONE stage inside the timed region (bench.py's roofline)
     int timing_stage = -1;
     std::vector<hipEvent_t> tev;  // pool: pairs (start, stop)
@@ -353,6 +362,35 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     return VH_OK;
 }
 
+// one complete forward of `batch` images on the context's stream(s): the (optional) concurrent parts are forked
+// from and joined back into c->stream, so everything that follows on c->stream sees the finished logits
+int enqueue_step(vh_ctx* c, const float* in, int batch, float* logits) {
+    const size_t img_floats = (size_t)c->cfg.image_size * c->cfg.image_size * c->cfg.channels;
+    const int parts = c->ln_fold ? 1 : (batch < c->nstreams ? batch : c->nstreams);
+    int rc;
+    if (parts > 1) {
+        // contiguous parts of the batch on different streams: the HBM-bound stages and the partly filled
+        // tail rounds of one part overlap the MFMA-bound stages of another (identical results: images
+        // are independent and every per-row reduction has a fixed order)
+        HIPCHK(&c->err, hipEventRecord(c->ev_fork, c->stream));
+        int b0 = 0;
+        for (int p = 0; p < parts; ++p) {
+            const int nb = batch / parts + (p < batch % parts ? 1 : 0);
+            hipStream_t st = p == 0 ? c->stream : c->xstream[p - 1];
+            if (p) HIPCHK(&c->err, hipStreamWaitEvent(st, c->ev_fork, 0));
+            if ((rc = enqueue_forward(c, in + (size_t)b0 * img_floats, nb, logits + (size_t)b0 * c->cfg.classes, nullptr, st, b0))) return rc;
+            if (p) {
+                HIPCHK(&c->err, hipEventRecord(c->ev_join[p - 1], st));
+                HIPCHK(&c->err, hipStreamWaitEvent(c->stream, c->ev_join[p - 1], 0));
+            }
+            b0 += nb;
+        }
+        c->last_batch = batch;
+        return VH_OK;
+    }
+    return enqueue_forward(c, in, batch, logits, nullptr, c->stream, 0);
+}
+
 int check_forward_args(vh_ctx* c, const void* in, int batch, const void* out) {
     if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
     if (!in || !out) return fail(&c->err, VH_ERR_INVALID, "null buffer");
@@ -366,6 +404,8 @@ int check_forward_args(vh_ctx* c, const void* in, int batch, const void* out) {
 
 // =================================================================================================
 extern "C" {
+
+int vh_ring_destroy(vh_ctx* c);
 
 int vh_abi_version(void) { return VH_ABI_VERSION; }
 
@@ -499,6 +539,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
 int vh_destroy(vh_ctx* c) {
     if (!c) return VH_OK;
     hipSetDevice(c->device);
+    vh_ring_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->arena) hipFree(c->arena);
     if (c->w16) hipFree(c->w16);
@@ -616,31 +657,8 @@ int vh_forward_device_async(vh_ctx* c, const float* in, int batch, float* logits
     HIPCHK(&c->err, hipSetDevice(c->device));
     c->tev_used = 0;
     HIPCHK(&c->err, hipEventRecord(c->ev0, c->stream));
-    const size_t img_floats = (size_t)c->cfg.image_size * c->cfg.image_size * c->cfg.channels;
-    for (int i = 0; i < steps; ++i) {
-        const int parts = c->ln_fold ? 1 : (batch < c->nstreams ? batch : c->nstreams);
-        if (parts > 1) {
-            // contiguous parts of the batch on different streams: the HBM-bound stages and the partly filled
-            // tail rounds of one part overlap the MFMA-bound stages of another (identical results: images
-            // are independent and every per-row reduction has a fixed order)
-            HIPCHK(&c->err, hipEventRecord(c->ev_fork, c->stream));
-            int b0 = 0;
-            for (int p = 0; p < parts; ++p) {
-                const int nb = batch / parts + (p < batch % parts ? 1 : 0);
-                hipStream_t st = p == 0 ? c->stream : c->xstream[p - 1];
-                if (p) HIPCHK(&c->err, hipStreamWaitEvent(st, c->ev_fork, 0));
-                if ((rc = enqueue_forward(c, in + (size_t)b0 * img_floats, nb, logits + (size_t)b0 * c->cfg.classes, nullptr, st, b0))) return rc;
-                if (p) {
-                    HIPCHK(&c->err, hipEventRecord(c->ev_join[p - 1], st));
-                    HIPCHK(&c->err, hipStreamWaitEvent(c->stream, c->ev_join[p - 1], 0));
-                }
-                b0 += nb;
-            }
-            c->last_batch = batch;
-        } else if ((rc = enqueue_forward(c, in, batch, logits, nullptr, c->stream, 0))) {
-            return rc;
-        }
-    }
+    for (int i = 0; i < steps; ++i)
+        if ((rc = enqueue_step(c, in, batch, logits))) return rc;
     HIPCHK(&c->err, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return VH_OK;
@@ -727,6 +745,119 @@ int vh_profile_forward(vh_ctx* c, const float* in, int batch, float* logits, dou
     for (auto& p : ev) hipEventDestroy(p.second);
     if (n_written) *n_written = ST_COUNT;
     return rc;
+}
+
+// ---- pipelined host path: a ring of in-flight batches ---------------------------------------------------------------
+// Modelled on the one asynchronous pattern the reference has, the 24-slot image ring of filter_image /
+// get_filtered_image (netFPGA.cpp:292-365, ring state :47-56): submit enqueues H2D copy -> forward -> D2H copy of
+// one batch into the next free slot and returns; collect waits for the OLDEST slot.  The copies run on their own
+// streams, so the upload of batch i+1 and the download of batch i-1 overlap the forward of batch i.  A full ring on
+// submit / an empty ring on collect are reported as errors (the reference prints "PILA LLENA" / "PILA VACIA" and
+// drops the frame, :330-333, :358-361).
+int vh_ring_destroy(vh_ctx* c) {
+    if (!c) return VH_OK;
+    if (c->ring.empty() && !c->copy_in) return VH_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->copy_in) hipStreamSynchronize(c->copy_in);
+    if (c->copy_out) hipStreamSynchronize(c->copy_out);
+    for (auto& s : c->ring) {
+        if (s.h_in) hipHostFree(s.h_in);
+        if (s.h_out) hipHostFree(s.h_out);
+        if (s.d_in) hipFree(s.d_in);
+        if (s.d_out) hipFree(s.d_out);
+        if (s.in_done) hipEventDestroy(s.in_done);
+        if (s.fwd_done) hipEventDestroy(s.fwd_done);
+        if (s.out_done) hipEventDestroy(s.out_done);
+    }
+    c->ring.clear();
+    if (c->copy_in) hipStreamDestroy(c->copy_in);
+    if (c->copy_out) hipStreamDestroy(c->copy_out);
+    c->copy_in = c->copy_out = nullptr;
+    c->ring_batch = c->ring_wr = c->ring_rd = c->ring_used = 0;
+    return VH_OK;
+}
+
+int vh_ring_create(vh_ctx* c, int slots, int batch_per_slot) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    if (slots < 1 || slots > 64) return fail(&c->err, VH_ERR_INVALID, "slots must be 1..64");
+    if (batch_per_slot < 1 || batch_per_slot > c->cfg.max_batch)
+        return fail(&c->err, VH_ERR_INVALID, "batch_per_slot %d outside 1..max_batch=%d", batch_per_slot, c->cfg.max_batch);
+    vh_ring_destroy(c);
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)batch_per_slot * c->cfg.image_size * c->cfg.image_size * c->cfg.channels * 4;
+    const size_t out_bytes = (size_t)batch_per_slot * c->cfg.classes * 4;
+    HIPCHK(&c->err, hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+    HIPCHK(&c->err, hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+    c->ring.resize(slots);
+    for (auto& s : c->ring) {
+        hipError_t e = hipHostMalloc((void**)&s.h_in, in_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_out, out_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.d_in, in_bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.d_out, out_bytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.in_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.fwd_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.out_done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            vh_ring_destroy(c);
+            return fail(&c->err, VH_ERR_HIP, "vh_ring_create: %s", hipGetErrorString(e));
+        }
+    }
+    c->ring_batch = batch_per_slot;
+    return VH_OK;
+}
+
+int vh_ring_free_slots(const vh_ctx* c, int* n) {
+    if (!c || !n) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *n = (int)c->ring.size() - c->ring_used;
+    return VH_OK;
+}
+
+int vh_ring_input(vh_ctx* c, float** pinned_in) {
+    if (!c || !pinned_in) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (c->ring.empty()) return fail(&c->err, VH_ERR_STATE, "no ring: call vh_ring_create first");
+    if (c->ring_used == (int)c->ring.size()) return fail(&c->err, VH_ERR_RING_FULL, "ring full (PILA LLENA)");
+    *pinned_in = c->ring[c->ring_wr].h_in;
+    return VH_OK;
+}
+
+int vh_ring_submit(vh_ctx* c, const float* in_host, int batch) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    if (c->ring.empty()) return fail(&c->err, VH_ERR_STATE, "no ring: call vh_ring_create first");
+    if (!c->weights_ready) return fail(&c->err, VH_ERR_STATE, "submit before weights were loaded");
+    if (batch < 1 || batch > c->ring_batch) return fail(&c->err, VH_ERR_INVALID, "batch %d outside 1..%d", batch, c->ring_batch);
+    if (c->ring_used == (int)c->ring.size()) return fail(&c->err, VH_ERR_RING_FULL, "ring full (PILA LLENA)");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    vh_ctx::RingSlot& s = c->ring[c->ring_wr];
+    const size_t in_bytes = (size_t)batch * c->cfg.image_size * c->cfg.image_size * c->cfg.channels * 4;
+    if (in_host && in_host != s.h_in) memcpy(s.h_in, in_host, in_bytes);  // NULL / the slot's own buffer: already filled in place
+    s.batch = batch;
+    HIPCHK(&c->err, hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, c->copy_in));
+    HIPCHK(&c->err, hipEventRecord(s.in_done, c->copy_in));
+    HIPCHK(&c->err, hipStreamWaitEvent(c->stream, s.in_done, 0));
+    int rc = enqueue_step(c, s.d_in, batch, s.d_out);
+    if (rc) return rc;
+    HIPCHK(&c->err, hipEventRecord(s.fwd_done, c->stream));
+    HIPCHK(&c->err, hipStreamWaitEvent(c->copy_out, s.fwd_done, 0));
+    HIPCHK(&c->err, hipMemcpyAsync(s.h_out, s.d_out, (size_t)batch * c->cfg.classes * 4, hipMemcpyDeviceToHost, c->copy_out));
+    HIPCHK(&c->err, hipEventRecord(s.out_done, c->copy_out));
+    c->ring_wr = (c->ring_wr + 1) % (int)c->ring.size();
+    ++c->ring_used;
+    return VH_OK;
+}
+
+int vh_ring_collect(vh_ctx* c, float* logits_host, int* batch) {
+    if (!c || !logits_host) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (c->ring.empty()) return fail(&c->err, VH_ERR_STATE, "no ring: call vh_ring_create first");
+    if (c->ring_used == 0) return fail(&c->err, VH_ERR_RING_EMPTY, "ring empty (PILA VACIA)");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    vh_ctx::RingSlot& s = c->ring[c->ring_rd];
+    HIPCHK(&c->err, hipEventSynchronize(s.out_done));
+    memcpy(logits_host, s.h_out, (size_t)s.batch * c->cfg.classes * 4);
+    if (batch) *batch = s.batch;
+    c->ring_rd = (c->ring_rd + 1) % (int)c->ring.size();
+    --c->ring_used;
+    return VH_OK;
 }
 
 int vh_set_streams(vh_ctx* c, int n) {

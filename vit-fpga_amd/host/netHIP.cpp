@@ -46,7 +46,7 @@ namespace hip
         : n_ins((int)data.n_ins), n_layers((int)data.n_p_l.size()), n_p_l(nullptr), n_neurons(0), n_params(0),
           params(nullptr), activations(VH_ACT_RELU2), bias(nullptr), n_sets(0), gradient_init(false),
           gradient_performance(0), forward_performance(0), device_init(false), device(0), vit_mode(false),
-          vcfg(), vit_seed(0), mlp(nullptr), vit(nullptr)
+          vcfg(), vit_seed(0), ring_slots(0), ring_batch(0), mlp(nullptr), vit(nullptr)
     {
         (void)derivate; // ignored by the reference as well
         if (n_layers <= 0 || n_ins <= 0)
@@ -93,7 +93,7 @@ namespace hip
         : n_ins((int)floats_per_image(cfg)), n_layers(cfg.layers), n_p_l(nullptr), n_neurons(0), n_params(0), params(nullptr),
           activations(VH_ACT_GELU), bias(nullptr), n_sets(0), gradient_init(false), gradient_performance(0),
           forward_performance(0), device_init(false), device(device_index), vit_mode(true), vcfg(cfg), vit_seed(seed),
-          mlp(nullptr), vit(nullptr)
+          ring_slots(0), ring_batch(0), mlp(nullptr), vit(nullptr)
     {
         if (vh_weight_blob_bytes(&vcfg) == 0)
             die("constructor", "unsupported vh_config");
@@ -132,6 +132,7 @@ namespace hip
         gradient_init = rh.gradient_init; gradient_performance = rh.gradient_performance;
         forward_performance = rh.forward_performance; device_init = rh.device_init; device = rh.device;
         vit_mode = rh.vit_mode; vcfg = rh.vcfg; vit_seed = rh.vit_seed; vit_blob = std::move(rh.vit_blob);
+        ring_slots = rh.ring_slots; ring_batch = rh.ring_batch;
         mlp = rh.mlp; vit = rh.vit;
         rh.n_p_l = nullptr; rh.params = nullptr; rh.bias = nullptr; rh.mlp = nullptr; rh.vit = nullptr;
         rh.device_init = false;
@@ -143,6 +144,7 @@ namespace hip
         activations = rh.activations; n_sets = rh.n_sets; gradient_init = rh.gradient_init;
         gradient_performance = rh.gradient_performance; forward_performance = rh.forward_performance;
         device = rh.device; vit_mode = rh.vit_mode; vcfg = rh.vcfg; vit_seed = rh.vit_seed; vit_blob = rh.vit_blob;
+        ring_slots = rh.ring_slots; ring_batch = rh.ring_batch;
         if (!vit_mode)
         {
             n_p_l = new int[n_layers];
@@ -249,7 +251,75 @@ namespace hip
                                         : vh_load_weights(vit, vit_blob.data(), vit_blob.size());
         if (rc != VH_OK)
             die("weights", vh_last_error(vit));
+        if (ring_slots > 0 && vh_ring_create(vit, ring_slots, ring_batch) != VH_OK)
+            die("vh_ring_create", vh_last_error(vit));
         device_init = true;
+    }
+
+    // ---- pipelined forward (ViT mode) ----
+    void net_hip::set_pipeline(int slots, int max_batch_per_slot)
+    {
+        if (!vit_mode)
+            die("set_pipeline", "only available in ViT mode");
+        if (slots < 1 || slots > 64 || max_batch_per_slot < 1)
+            die("set_pipeline", "slots must be 1..64 and max_batch_per_slot positive");
+        if (vit)
+        {
+            int free_slots = 0;
+            if (ring_slots > 0 && vh_ring_free_slots(vit, &free_slots) == VH_OK && free_slots != ring_slots)
+                die("set_pipeline", "batches still in flight: collect them first");
+            vh_destroy(vit);
+            vit = nullptr;
+            device_init = false;
+        }
+        ring_slots = slots;
+        ring_batch = max_batch_per_slot;
+    }
+
+    bool net_hip::submit_forward(const vector<DATA_TYPE> &inputs)
+    {
+        if (!vit_mode || ring_slots == 0)
+            die("submit_forward", "call set_pipeline first (ViT mode)");
+        if (inputs.empty() || inputs.size() % (size_t)n_ins != 0)
+            die("submit_forward", "inputs.size() must be a positive multiple of n_ins");
+        const int count = (int)(inputs.size() / (size_t)n_ins);
+        if (count > ring_batch)
+            die("submit_forward", "more images than a pipeline slot holds");
+        ensure_device(ring_batch);
+        const int rc = vh_ring_submit(vit, inputs.data(), count);
+        if (rc == VH_ERR_RING_FULL)
+        {
+            cout << "PILA LLENA\n"; // the reference's own overflow report (netFPGA.cpp:358-361); the batch is not queued
+            return false;
+        }
+        if (rc != VH_OK)
+            die("vh_ring_submit", vh_last_error(vit));
+        return true;
+    }
+
+    vector<DATA_TYPE> net_hip::collect_forward()
+    {
+        if (!vit_mode || ring_slots == 0)
+            die("collect_forward", "call set_pipeline first (ViT mode)");
+        vector<DATA_TYPE> out;
+        if (!vit)
+        {
+            cout << "PILA VACIA\n";
+            return out;
+        }
+        out.resize((size_t)ring_batch * vcfg.classes);
+        int count = 0;
+        const int rc = vh_ring_collect(vit, out.data(), &count);
+        if (rc == VH_ERR_RING_EMPTY)
+        {
+            cout << "PILA VACIA\n"; // netFPGA.cpp:330-333
+            out.clear();
+            return out;
+        }
+        if (rc != VH_OK)
+            die("vh_ring_collect", vh_last_error(vit));
+        out.resize((size_t)count * vcfg.classes);
+        return out;
     }
 
     vector<DATA_TYPE> net_hip::launch_forward(const vector<DATA_TYPE> &inputs)

@@ -57,6 +57,7 @@ namespace hip
         bool vit_mode;
         vh_config vcfg;
         uint64_t vit_seed;
+        int ring_slots, ring_batch; // 0 = no pipeline
         std::string vit_blob;  // host copy of the canonical blob when constructed from one
         vh_mlp *mlp;
         vh_ctx *vit;
@@ -90,6 +91,12 @@ namespace hip
         void set_activation(int vh_act_code);       // MLP mode, before the first forward
         size_t vit_param_count() const;             // ViT mode: number of fp32 parameters
         double last_kernel_ms();                    // ViT mode: device time of the last forward
+        // ViT mode, pipelined: the shape of filter_image/get_filtered_image (netFPGA.cpp:292-365) applied to
+        // launch_forward.  submit_forward returns false when every slot is in flight ("PILA LLENA"),
+        // collect_forward returns an empty vector when nothing is ("PILA VACIA"); results come back in FIFO order.
+        void set_pipeline(int slots, int max_batch_per_slot);
+        bool submit_forward(const std::vector<DATA_TYPE> &inputs);
+        std::vector<DATA_TYPE> collect_forward();
     };
 }
 

@@ -65,6 +65,12 @@ SYMBOLS = {
     "vh_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double)]),
     "vh_profile_forward": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_double), _i, _pi]),
     "vh_stage_name": (C.c_char_p, [_i]),
+    "vh_ring_create": (_i, [_vp, _i, _i]),
+    "vh_ring_destroy": (_i, [_vp]),
+    "vh_ring_free_slots": (_i, [_vp, _pi]),
+    "vh_ring_input": (_i, [_vp, C.POINTER(C.POINTER(C.c_float))]),
+    "vh_ring_submit": (_i, [_vp, _vp, _i]),
+    "vh_ring_collect": (_i, [_vp, _vp, _pi]),
     "vh_set_streams": (_i, [_vp, _i]),
     "vh_get_streams": (_i, [_vp, _pi]),
     "vh_set_stage_timing": (_i, [_vp, _i]),
@@ -258,6 +264,36 @@ class VitContext:
         nw = C.c_int(0)
         _check(lib().vh_profile_forward(self.h, in_ptr, batch, out_ptr, arr, 2 * n, C.byref(nw)), self.h)
         return {STAGES[i]: (arr[i], int(arr[n + i])) for i in range(n)}
+
+    # ---- pipelined host path (ring of in-flight batches) ----
+    def ring_create(self, slots, batch_per_slot):
+        _check(lib().vh_ring_create(self.h, slots, batch_per_slot), self.h)
+        self._ring_batch = batch_per_slot
+
+    def ring_free_slots(self):
+        n = C.c_int(0)
+        _check(lib().vh_ring_free_slots(self.h, C.byref(n)), self.h)
+        return n.value
+
+    def ring_input(self, batch):
+        """numpy view of the pinned staging buffer the next submit will use."""
+        p = C.POINTER(C.c_float)()
+        _check(lib().vh_ring_input(self.h, C.byref(p)), self.h)
+        n = batch * self.cfg["image_size"] ** 2 * self.cfg["channels"]
+        return np.ctypeslib.as_array(p, shape=(n,)).reshape(batch, self.cfg["image_size"], self.cfg["image_size"], self.cfg["channels"])
+
+    def ring_submit(self, images=None, batch=None):
+        if images is None:
+            _check(lib().vh_ring_submit(self.h, None, batch), self.h)
+        else:
+            images = np.ascontiguousarray(images, dtype=np.float32)
+            _check(lib().vh_ring_submit(self.h, images.ctypes.data, images.shape[0]), self.h)
+
+    def ring_collect(self):
+        out = np.empty((self._ring_batch, self.cfg["classes"]), dtype=np.float32)
+        nb = C.c_int(0)
+        _check(lib().vh_ring_collect(self.h, out.ctypes.data, C.byref(nb)), self.h)
+        return out[:nb.value]
 
     def set_streams(self, n):
         _check(lib().vh_set_streams(self.h, n), self.h)
