@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "vit-fpga_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0}  # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp8": 5000.0}  # dense MFMA peak, MI355X_MICROARCH.md
 
 
 def main():
@@ -36,7 +36,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="images per GPU")
     ap.add_argument("--config", default="vit_base")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp8"],
+                    help="fp8 = BASELINE config 5: e4m3 operands for the four per-layer GEMMs (bf16 elsewhere)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even with one rank")
@@ -64,7 +65,7 @@ def main():
     import vithip
 
     cfg = S.CONFIGS[args.config]
-    dt = vithip.DTYPE_BF16 if args.dtype == "bf16" else vithip.DTYPE_FP16
+    dt = {"bf16": vithip.DTYPE_BF16, "fp16": vithip.DTYPE_FP16, "fp8": vithip.DTYPE_FP8}[args.dtype]
     B = args.batch
     ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B, device=local_rank)
     if args.streams > 0:
@@ -145,8 +146,8 @@ def main():
         achieved = fc1_flops / (fc1_avg_ms * 1e-3) / 1e12 if fc1_avg_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
         out = {
-            "metric": "images/sec ViT-B/16 224x224, batch 512 per GPU" if args.config == "vit_base" and B == 512
-                      else f"images/sec {args.config} batch {B} per GPU",
+            "metric": "images/sec ViT-B/16 224x224, batch 512 per GPU" if args.config == "vit_base" and B == 512 and args.dtype == "bf16"
+                      else f"images/sec {args.config} {args.dtype} batch {B} per GPU",
             "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -156,7 +157,8 @@ def main():
                        "parallelism": f"image-sharded x{world}, weights RCCL-broadcast once, no data-path collective",
                        "flop_per_image": flops_img},
             "forward_mfma_frac": round(ips / world * flops_img / (peak * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_pp_kernel<bias+GELU> 256x256x64 ping-pong (fc1)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_pp_kernel<bias+GELU> 256x256x64 ping-pong (fc1)" if args.dtype != "fp8"
+                                   else "gemm_nt_pp_kernel<bias+GELU, e4m3> 256x256x128 ping-pong (fc1)",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "concurrent_parts": streams,
                          "flop_per_launch": fc1_flops, "avg_launch_ms": round(fc1_avg_ms, 5),

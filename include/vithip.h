@@ -43,6 +43,11 @@ extern "C" {
 /* arithmetic type of the dense contractions (MFMA operand type; accumulation is fp32) */
 #define VH_DTYPE_BF16 0
 #define VH_DTYPE_FP16 1
+/* fp8 GEMMs (BASELINE config 5): the four per-layer GEMMs run on v_mfma_scale_f32_16x16x128_f8f6f4 with OCP
+ * e4m3 operands -- weights quantised at load with one fp32 scale per output channel, activations cast unscaled
+ * (saturating at +-448) by the kernel that produces them; fp32 accumulation, fp32 residual stream; patch embedding,
+ * attention and the head stay bf16.  Needs dim % 128 == 0 and mlp_dim % 128 == 0. */
+#define VH_DTYPE_FP8 2
 
 /* activation selector of MLP mode.  The reference stores `activations = 1 // RELU2`
  * (netFPGA.cpp:79) but never defines it (the network_v1 kernel source is absent), so the
@@ -192,6 +197,16 @@ int vh_debug_set_layers(vh_ctx* ctx, int n_layers);
 int vh_op_gemm(const void* a16_dev, const void* w16_dev, const float* bias_dev, void* out_dev,
                int64_t M, int N, int K, int epilogue, const float* aux_dev, int aux_i,
                int dtype, int variant, void* stream);
+
+/* fp8 GEMM (VH_DTYPE_FP8 path): a8 [M,K], w8 [N,K] OCP e4m3 bytes, w_scale [N] fp32 (per output channel),
+ * out = epilogue(w_scale[n] * sum_k a8[m,k] w8[n,k] + bias[n]);  VH_EPI_BIAS -> bf16, VH_EPI_BIAS_GELU -> e4m3
+ * (saturating), VH_EPI_BIAS_RESID (out += ...) / VH_EPI_BIAS_F32 -> fp32.  K % 128 == 0, N % 4 == 0. */
+int vh_op_gemm_fp8(const void* a8, const void* w8, const float* w_scale, const float* bias, void* out, int64_t M,
+                   int N, int K, int epilogue, void* stream);
+/* the load-time weight quantiser: s0 = amax(row)/448 (1 for an all-zero row), w8 = rne_e4m3(w / s0),
+ * scale[row] = s0 * post_scale */
+int vh_op_quantize_rows(const float* w, int rows, int cols, float post_scale, void* w8, float* scale, void* stream);
+
 /* same with the operands of the LayerNorm-folding epilogues: stats [M][2] = (mean, rstd) for LNFOLD*,
  * out16 [M,N] and partials [N/64][M][2] for RESID_LN (N must be a multiple of 256) */
 int vh_op_gemm_ex(const void* a16_dev, const void* w16_dev, const float* bias_dev, void* out_dev,

@@ -52,6 +52,21 @@ int oracle_vit_make_blob(const oracle_vit_config* c, uint64_t seed, void* blob, 
 int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float* in_nhwc,
                        int batch, float* logits, float* hidden, int n_layers_run, int threads);
 
+/* The same forward with the data flow of the device's VH_DTYPE_FP8 mode emulated (BASELINE config 5): the four
+ * per-layer GEMMs take OCP e4m3 operands -- weights quantised per output channel, activations cast unscaled and
+ * saturating -- with fp32 accumulation; qkv rounded to bf16; everything else fp32.  A quantised pipeline is
+ * chaotic (a last-bit difference before a cast flips a 6 % rounding), so this pins the device STATISTICALLY: the
+ * device must be as close to the fp32 forward as this emulation is (tests/test_gpu_fp8.py). */
+int oracle_vit_forward_fp8(const oracle_vit_config* c, const void* blob, const float* in_nhwc,
+                           int batch, float* logits, float* hidden, int n_layers_run, int threads);
+/* e4m3fn: round-to-nearest-even, saturating at +-448 */
+uint8_t oracle_e4m3_from_float(float f);
+float oracle_e4m3_to_float(uint8_t b);
+void oracle_quant_e4m3(float* x, int64_t n); /* in place: x -> decode(encode(x)) */
+/* s0 = amax(row)/448 (1 for a zero row); w8 = e4m3(w/s0) (bytes, optional), wq = decoded (optional),
+ * scale[row] = s0*post */
+void oracle_quantize_rows(const float* w, int rows, int cols, float post, uint8_t* w8, float* wq, float* scale);
+
 /* ---- single operators (for per-kernel parity tests) ------------------------------------- */
 /* out[m,n] = sum_k a[m,k]*w[n,k] + bias[n]   (bias may be NULL) */
 void oracle_linear(const float* a, const float* w, const float* bias, float* out, int64_t M,

@@ -278,8 +278,69 @@ void oracle_round_fp16(float* x, int64_t n) {
 /* ------------------------------------------------------------------------------------- */
 /* forward                                                                               */
 /* ------------------------------------------------------------------------------------- */
-int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float* in,
-                       int batch, float* logits, float* hidden, int n_layers_run, int threads) {
+/* ---- OCP e4m3fn (fp8 path, include/vithip.h VH_DTYPE_FP8) ------------------------------------
+ * Round-to-nearest-even, saturating at +-448 (the device clamps before v_cvt_pk_fp8_f32, which itself
+ * rounds to nearest even: tools/probe_fp8.hip checks this routine against the instruction on 2e5 values). */
+float oracle_e4m3_to_float(uint8_t b) {
+    const int sg = b >> 7, e = (b >> 3) & 15, m = b & 7;
+    float v;
+    if (e == 15 && m == 7) v = NAN;
+    else if (e == 0) v = ldexpf((float)m, -9);
+    else v = ldexpf(1.0f + (float)m / 8.0f, e - 7);
+    return sg ? -v : v;
+}
+uint8_t oracle_e4m3_from_float(float f) {
+    if (isnan(f)) return 0x7F;
+    const uint8_t sg = signbit(f) ? 0x80 : 0;
+    const float a = fabsf(f);
+    if (a >= 448.f) return sg | 0x7E;
+    if (a < ldexpf(1.0f, -10)) return sg;          /* below half the smallest subnormal; the tie 2^-10 goes to even = 0 */
+    int e;
+    (void)frexpf(a, &e);
+    int ex = e - 1;                                  /* a = 1.x * 2^ex */
+    if (ex < -6) ex = -6;
+    const float q = ldexpf(1.0f, ex - 3);            /* spacing of e4m3 at this magnitude */
+    const float v = nearbyintf(a / q) * q;           /* exact: a/q is a small dyadic number; default mode = RNE */
+    if (v >= 448.f) return sg | 0x7E;
+    if (v < ldexpf(1.0f, -6)) return sg | (uint8_t)(int)(v / ldexpf(1.0f, -9));
+    (void)frexpf(v, &e);
+    ex = e - 1;
+    const int m = (int)((v / ldexpf(1.0f, ex) - 1.0f) * 8.0f);
+    return sg | (uint8_t)(((ex + 7) << 3) | m);
+}
+void oracle_quant_e4m3(float* x, int64_t n) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) x[i] = oracle_e4m3_to_float(oracle_e4m3_from_float(x[i]));
+}
+/* the load-time weight quantiser (vh_op_quantize_rows): s0 = amax/448 (1 for a zero row), w8 = e4m3(w / s0),
+ * scale = s0 * post.  w8 and wq (the decoded values, optional) may be NULL. */
+void oracle_quantize_rows(const float* w, int rows, int cols, float post, uint8_t* w8, float* wq, float* scale) {
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; ++r) {
+        const float* wr = w + (size_t)r * cols;
+        float amax = 0.f;
+        for (int k = 0; k < cols; ++k) { const float a = fabsf(wr[k]); if (a > amax) amax = a; }
+        const float s0 = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+        for (int k = 0; k < cols; ++k) {
+            const uint8_t b = oracle_e4m3_from_float(wr[k] / s0);
+            if (w8) w8[(size_t)r * cols + k] = b;
+            if (wq) wq[(size_t)r * cols + k] = oracle_e4m3_to_float(b);
+        }
+        scale[r] = s0 * post;
+    }
+}
+
+/* out[m,n] = scale[n] * sum_k a[m,k] wq[n,k] + bias[n] */
+static void linear_scaled(const float* a, const float* wq, const float* scale, const float* bias, float* out,
+                          int64_t M, int N, int K) {
+    oracle_linear(a, wq, NULL, out, M, N, K);
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) out[m * N + n] = out[m * N + n] * scale[n] + bias[n];
+}
+
+static int vit_forward_impl(const oracle_vit_config* c, const void* blob, const float* in,
+                       int batch, float* logits, float* hidden, int n_layers_run, int threads, int fp8) {
     blob_header h;
     memcpy(&h, blob, sizeof h);
     if (memcmp(h.magic, "VHBLOB1", 8) != 0) return 1;
@@ -317,6 +378,14 @@ int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float
     float* wqkv = (float*)malloc(sizeof(float) * 3 * (size_t)D * D);
     float* bqkv = (float*)malloc(sizeof(float) * 3 * (size_t)D);
     if (!x || !y || !qkv || !att || !hid || !col || !pw || !wqkv || !bqkv) return 3;
+    /* fp8 emulation: decoded e4m3 weights (largest matrix: mlp x dim) and their per-row scales */
+    float *wq8 = NULL, *wsc = NULL;
+    if (fp8) {
+        const size_t big = (size_t)(Mh > 3 * D ? Mh : 3 * D) * D;
+        wq8 = (float*)malloc(sizeof(float) * big);
+        wsc = (float*)malloc(sizeof(float) * (size_t)(Mh > 3 * D ? Mh : 3 * D));
+        if (!wq8 || !wsc) return 3;
+    }
 
     /* conv kernel [D][c][ky][kx] -> [D][ky][kx][c] so that it meets the NHWC patch rows */
     for (int d = 0; d < D; ++d)
@@ -361,6 +430,32 @@ int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float
         memcpy(bqkv + D, kb, sizeof(float) * D);
         memcpy(bqkv + 2 * D, vb, sizeof(float) * D);
 
+        if (fp8) {
+            /* the device's VH_DTYPE_FP8 data flow: every GEMM operand is e4m3 (weights with a per-row scale,
+             * activations unscaled), fp32 accumulation, qkv stored as bf16, fp32 residual stream */
+            oracle_layernorm(x, rows, D, ln1w, ln1b, c->ln_eps, y);
+            oracle_quant_e4m3(y, rows * D);
+            oracle_quantize_rows(wqkv, 3 * D, D, 1.0f, NULL, wq8, wsc);
+            linear_scaled(y, wq8, wsc, bqkv, qkv, rows, 3 * D, D);
+            oracle_round_bf16(qkv, rows * 3 * D);
+            oracle_attention(qkv, batch, T, H, dh, att);
+            oracle_quant_e4m3(att, rows * D);
+            oracle_quantize_rows(ow, D, D, 1.0f, NULL, wq8, wsc);
+            linear_scaled(att, wq8, wsc, ob, y, rows, D, D);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < rows * D; ++i) x[i] += y[i];
+            oracle_layernorm(x, rows, D, ln2w, ln2b, c->ln_eps, y);
+            oracle_quant_e4m3(y, rows * D);
+            oracle_quantize_rows(f1w, Mh, D, 1.0f, NULL, wq8, wsc);
+            linear_scaled(y, wq8, wsc, f1b, hid, rows, Mh, D);
+            oracle_gelu(hid, rows * Mh);
+            oracle_quant_e4m3(hid, rows * Mh);
+            oracle_quantize_rows(f2w, D, Mh, 1.0f, NULL, wq8, wsc);
+            linear_scaled(hid, wq8, wsc, f2b, y, rows, D, Mh);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < rows * D; ++i) x[i] += y[i];
+            continue;
+        }
         oracle_layernorm(x, rows, D, ln1w, ln1b, c->ln_eps, y);
         oracle_linear(y, wqkv, bqkv, qkv, rows, 3 * D, D);
         oracle_attention(qkv, batch, T, H, dh, att);
@@ -382,5 +477,15 @@ int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float
     oracle_linear(y, fin + 2 * D, fin + 2 * D + (size_t)C * D, logits, batch, C, D);
 
     free(x); free(y); free(qkv); free(att); free(hid); free(col); free(pw); free(wqkv); free(bqkv);
+    free(wq8); free(wsc);
     return 0;
+}
+
+int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float* in,
+                       int batch, float* logits, float* hidden, int n_layers_run, int threads) {
+    return vit_forward_impl(c, blob, in, batch, logits, hidden, n_layers_run, threads, 0);
+}
+int oracle_vit_forward_fp8(const oracle_vit_config* c, const void* blob, const float* in,
+                           int batch, float* logits, float* hidden, int n_layers_run, int threads) {
+    return vit_forward_impl(c, blob, in, batch, logits, hidden, n_layers_run, threads, 1);
 }

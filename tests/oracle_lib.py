@@ -47,6 +47,16 @@ def lib():
         L.oracle_vit_forward.restype = C.c_int
         L.oracle_vit_forward.argtypes = [C.POINTER(OracleConfig), C.c_void_p, fp, C.c_int, fp, fp,
                                          C.c_int, C.c_int]
+        L.oracle_vit_forward_fp8.restype = C.c_int
+        L.oracle_vit_forward_fp8.argtypes = L.oracle_vit_forward.argtypes
+        L.oracle_e4m3_from_float.restype = C.c_uint8
+        L.oracle_e4m3_from_float.argtypes = [C.c_float]
+        L.oracle_e4m3_to_float.restype = C.c_float
+        L.oracle_e4m3_to_float.argtypes = [C.c_uint8]
+        L.oracle_quant_e4m3.restype = None
+        L.oracle_quant_e4m3.argtypes = [fp, C.c_int64]
+        L.oracle_quantize_rows.restype = None
+        L.oracle_quantize_rows.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_void_p, fp, fp]
         L.oracle_linear.restype = None
         L.oracle_linear.argtypes = [fp, fp, fp, fp, C.c_int64, C.c_int, C.c_int]
         L.oracle_gelu.restype = None
@@ -97,17 +107,43 @@ def make_blob(cfg, seed, ln_eps=1e-6):
     return blob
 
 
-def vit_forward(cfg, blob, images, n_layers=-1, threads=0, want_hidden=False, ln_eps=1e-6):
+def vit_forward(cfg, blob, images, n_layers=-1, threads=0, want_hidden=False, ln_eps=1e-6, fp8=False):
+    """fp8=True: the emulation of the device's VH_DTYPE_FP8 data flow (oracle.h, oracle_vit_forward_fp8)."""
     c = cfg_struct(cfg, ln_eps)
     images = _f32(images)
     batch = images.shape[0]
     logits = np.empty((batch, cfg["classes"]), dtype=np.float32)
     g = cfg["image_size"] // cfg["patch_size"]
     hidden = np.empty((batch * (1 + g * g), cfg["dim"]), dtype=np.float32) if want_hidden else None
-    rc = lib().oracle_vit_forward(C.byref(c), blob.ctypes.data, _fp(images), batch, _fp(logits),
-                                  _fp(hidden) if want_hidden else None, n_layers, threads)
+    fn = lib().oracle_vit_forward_fp8 if fp8 else lib().oracle_vit_forward
+    rc = fn(C.byref(c), blob.ctypes.data, _fp(images), batch, _fp(logits),
+            _fp(hidden) if want_hidden else None, n_layers, threads)
     assert rc == 0, rc
     return (logits, hidden) if want_hidden else logits
+
+
+def quant_e4m3(x):
+    """decode(encode(x)): x rounded to the nearest e4m3 value, saturating at +-448."""
+    x = _f32(x).copy()
+    lib().oracle_quant_e4m3(_fp(x), x.size)
+    return x
+
+
+def e4m3_bytes(x):
+    x = _f32(x)
+    f = lib().oracle_e4m3_from_float
+    return np.fromiter((f(float(v)) for v in x.ravel()), dtype=np.uint8, count=x.size).reshape(x.shape)
+
+
+def quantize_rows(w, post=1.0):
+    """-> (w8 bytes [rows, cols], decoded values fp32, scale [rows])"""
+    w = _f32(w)
+    rows, cols = w.shape
+    w8 = np.empty((rows, cols), dtype=np.uint8)
+    wq = np.empty((rows, cols), dtype=np.float32)
+    sc = np.empty(rows, dtype=np.float32)
+    lib().oracle_quantize_rows(_fp(w), rows, cols, post, w8.ctypes.data, _fp(wq), _fp(sc))
+    return w8, wq, sc
 
 
 def linear(a, w, bias=None):

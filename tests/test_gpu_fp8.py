@@ -1,0 +1,189 @@
+"""GPU parity of the fp8 path (BASELINE config 5: ViT-B/16, e4m3 GEMM operands on v_mfma_scale_f32_16x16x128_f8f6f4).
+
+What can be pinned exactly, is: the casts (bit-exact against the oracle's quantiser), the weight quantiser
+(bit-exact), and the GEMM on GIVEN e4m3 operands (fp32 accumulation: only the summation order differs).
+The end-to-end logits cannot be pinned to 1e-3: every cast rounds by up to 6 %, and a quantised pipeline is
+chaotic (a last-bit difference ahead of a cast flips a rounding), so two correct implementations of the same
+data flow drift apart to the fp8 noise level.  The end-to-end criterion is therefore statistical and written
+out in test_logits_*: the device must be as close to the fp32 oracle as the oracle's own emulation of the fp8
+data flow is (x1.5), and close to that emulation at the same level.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import vh_synth as S
+
+pytestmark = pytest.mark.gpu
+
+vithip = pytest.importorskip("vithip")
+FP8 = vithip.DTYPE_FP8
+_KEEP = []
+
+
+def dev(a):
+    b = vithip.DeviceBuffer.from_numpy(a)
+    _KEEP.append(b)
+    return b
+
+
+@pytest.fixture(autouse=True)
+def _release_buffers():
+    yield
+    for b in _KEEP:
+        b.free()
+    _KEEP.clear()
+
+
+def rel(got, ref):
+    return float(np.abs(got - ref).max() / np.abs(ref).max())
+
+
+def test_cast_is_bit_exact_e4m3_rne_saturating():
+    n = 1 << 18
+    x = (S.fill(n, 5, 9, 0) * np.exp2(np.floor(S.fill(n, 6, 9, 0) * 12))).astype(np.float32)
+    x[:8] = [448.0, -448.0, 449.0, 1e9, -1e9, 0.0, 2.0 ** -10, 3 * 2.0 ** -10]
+    out = vithip.DeviceBuffer(n)
+    vithip.op_cast(dev(x).ptr, out.ptr, n, FP8)
+    got = out.to_numpy(np.uint8, (n,))
+    want = O.e4m3_bytes(x)
+    same = (got == want) | ((x == 0) & ((got & 0x7F) == 0))      # -0 / +0
+    assert same.all(), np.flatnonzero(~same)[:10]
+
+
+def test_weight_quantiser_is_bit_exact():
+    rows, cols = 300, 768
+    w = S.fill(rows * cols, 11, 3, 1, 0.02).reshape(rows, cols)
+    w[7] = 0.0
+    w8 = vithip.DeviceBuffer(rows * cols)
+    sc = vithip.DeviceBuffer(rows * 4)
+    vithip.op_quantize_rows(dev(w).ptr, rows, cols, 0.125, w8.ptr, sc.ptr)
+    want8, _, want_sc = O.quantize_rows(w, post=0.125)
+    assert np.array_equal(sc.to_numpy(np.float32, (rows,)), want_sc)
+    got8 = w8.to_numpy(np.uint8, (rows, cols))
+    assert np.array_equal(got8 & 0x7F, want8 & 0x7F) and np.array_equal(got8[w != 0], want8[w != 0])
+
+
+def _operands(M, N, K, seed):
+    a = O.quant_e4m3((S.fill(M * K, seed, 1, 0) * 3.0).reshape(M, K))
+    w = S.fill(N * K, seed, 2, 1, 0.02).reshape(N, K)
+    w8, wq, sc = O.quantize_rows(w)
+    bias = S.fill(N, seed, 3, 1, 0.1)
+    return a, O.e4m3_bytes(a), w8, wq, sc, bias
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 260, 384), (1000, 768, 768), (64, 3072, 256), (5, 8, 128)])
+def test_gemm_fp32_out_matches_fp32_accumulation(M, N, K):
+    a, a8, w8, wq, sc, bias = _operands(M, N, K, 21)
+    ref = O.linear(a, wq) * sc[None, :] + bias[None, :]
+    out = vithip.DeviceBuffer(M * N * 4)
+    vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, out.ptr, M, N, K, vithip.EPI_BIAS_F32)
+    got = out.to_numpy(np.float32, (M, N))
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 2e-5 * scale, np.abs(got - ref).max() / scale
+    # residual form: out += ...
+    x0 = S.fill(M * N, 22, 4, 0).reshape(M, N)
+    xb = dev(x0)
+    vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, xb.ptr, M, N, K, vithip.EPI_BIAS_RESID)
+    got = xb.to_numpy(np.float32, (M, N))
+    assert np.abs(got - (x0 + ref)).max() <= 2e-5 * max(scale, 1.0)
+
+
+def test_gemm_integer_exact_asymmetric():
+    # small integers and halves are exact in e4m3 and in the fp32 accumulator: any lane-map mistake shows
+    M, N, K = 272, 264, 256
+    rng = np.random.default_rng(3)
+    a = rng.integers(-4, 5, size=(M, K)).astype(np.float32)
+    w = rng.integers(-3, 4, size=(N, K)).astype(np.float32) * 0.5
+    a[:, 0] += 8.0 * (np.arange(M) % 3)            # asymmetric in m
+    w[:, 1] += 1.0 * (np.arange(N) % 5)            # and in n
+    a, w = O.quant_e4m3(a), O.quant_e4m3(w)
+    sc = np.ones(N, np.float32)
+    bias = np.zeros(N, np.float32)
+    out = vithip.DeviceBuffer(M * N * 4)
+    vithip.op_gemm_fp8(dev(O.e4m3_bytes(a)).ptr, dev(O.e4m3_bytes(w)).ptr, dev(sc).ptr, dev(bias).ptr, out.ptr, M, N, K,
+                       vithip.EPI_BIAS_F32)
+    assert np.array_equal(out.to_numpy(np.float32, (M, N)), a.astype(np.float64) @ w.astype(np.float64).T)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (300, 260, 128), (197, 768, 768)])
+def test_gemm_bf16_and_gelu_e4m3_outputs(M, N, K):
+    a, a8, w8, wq, sc, bias = _operands(M, N, K, 31)
+    pre = O.linear(a, wq) * sc[None, :] + bias[None, :]
+    out16 = vithip.DeviceBuffer(M * N * 2)
+    vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, out16.ptr, M, N, K, vithip.EPI_BIAS)
+    got = vithip.from_bf16_bits(out16.to_numpy(np.uint16, (M, N)))
+    assert np.all(np.abs(got - pre) <= 2.0 ** -8 * np.abs(pre) * 1.01 + 2e-5 * np.abs(pre).max())
+    # fc1 form: gelu -> e4m3.  Compare decoded values: within one e4m3 step of the oracle's, almost all identical
+    # (fp32 summation order moves a value across a rounding boundary now and then)
+    out8 = vithip.DeviceBuffer(M * N)
+    vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, out8.ptr, M, N, K, vithip.EPI_BIAS_GELU)
+    got8 = vithip.from_e4m3(out8.to_numpy(np.uint8, (M, N)))
+    g = O.gelu(pre)
+    want8 = O.quant_e4m3(g)
+    assert np.isfinite(got8).all()
+    step = np.maximum(np.abs(want8), 2.0 ** -6) * 2.0 ** -3 + 1e-12
+    assert np.all(np.abs(got8 - want8) <= step * 1.001)
+    assert (got8 == want8).mean() >= 0.995, (got8 == want8).mean()
+
+
+def test_layernorm_and_attention_write_e4m3():
+    rows, dim = 333, 768
+    x = S.fill(rows * dim, 41, 1, 0).reshape(rows, dim) * 2.0
+    gm, bt = 1.0 + S.fill(dim, 41, 2, 1, 0.05), S.fill(dim, 41, 3, 1, 0.02)
+    out = vithip.DeviceBuffer(rows * dim)
+    vithip.op_layernorm(dev(x).ptr, rows, dim, dim, dev(gm).ptr, dev(bt).ptr, 1e-6, out.ptr, FP8)
+    got = vithip.from_e4m3(out.to_numpy(np.uint8, (rows, dim)))
+    ref = O.layernorm(x, gm, bt)
+    want = O.quant_e4m3(ref)
+    assert (got == want).mean() >= 0.999 and np.all(np.abs(got - ref) <= np.maximum(np.abs(ref), 2.0 ** -6) * 2.0 ** -4 * 1.05)
+    batch, tokens, heads = 2, 197, 4
+    D = heads * 64
+    qkv = O.round_bf16((S.fill(batch * tokens * 3 * D, 42, 1, 0) * 1.5).reshape(batch * tokens, 3 * D))
+    ref = O.attention(qkv, batch, tokens, heads)
+    pre = qkv.copy()
+    pre[:, :D] *= 0.125
+    o8 = vithip.DeviceBuffer(batch * tokens * D)
+    vithip.op_attention(dev(vithip.to16(pre, vithip.DTYPE_BF16)).ptr, batch, tokens, heads, o8.ptr, FP8)
+    got = vithip.from_e4m3(o8.to_numpy(np.uint8, (batch * tokens, D)))
+    assert np.isfinite(got).all()
+    # bf16 P/O rounding inside the kernel (1.2e-2, test_gpu_ops.ATT_TOL) plus half an e4m3 step on the way out
+    assert np.all(np.abs(got - ref) <= 2.0 ** -4 * np.abs(ref) + 1.2e-2 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name,batch", [("vit_q8", 4), ("vit_base", 2)])
+def test_logits_track_the_fp8_emulation_and_the_fp32_forward(name, batch):
+    cfg = S.CONFIGS[name]
+    blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, batch)
+    ref32 = O.vit_forward(cfg, blob, images)
+    emu = O.vit_forward(cfg, blob, images, fp8=True)
+    ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=batch)
+    ctx.load_weights(blob)
+    got = ctx.forward(images)
+    ctx.close()
+    e_emu32, e_gpu32, e_gpuemu = rel(emu, ref32), rel(got, ref32), rel(got, emu)
+    # normalised RMS is the steadier statistic of a noisy pipeline; max-norm is reported next to it
+    rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    r_emu32, r_gpu32, r_gpuemu = rms(emu, ref32), rms(got, ref32), rms(got, emu)
+    top1 = float((got.argmax(1) == ref32.argmax(1)).mean())
+    print(f"\n[fp8] {name} b{batch}: max-norm emu-fp32 {e_emu32:.3e} gpu-fp32 {e_gpu32:.3e} gpu-emu {e_gpuemu:.3e}; "
+          f"rms emu-fp32 {r_emu32:.3e} gpu-fp32 {r_gpu32:.3e} gpu-emu {r_gpuemu:.3e}; top1 agree {top1:.2f}")
+    assert np.isfinite(got).all()
+    assert r_gpu32 <= 1.5 * r_emu32 + 1e-3          # as close to the truth as the emulated data flow is
+    assert r_gpuemu <= 1.5 * r_emu32 + 1e-3         # and as close to the emulation
+    assert e_gpu32 <= 0.25                            # sanity bound in the max-norm
+
+
+def test_fp8_is_deterministic_batch_independent_and_rejects_bad_dims():
+    cfg = S.CONFIGS["vit_q8"]
+    ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=5)
+    ctx.init_weights_seeded(3)
+    images = S.make_images(cfg, 2, 5)
+    full = ctx.forward(images)
+    assert np.array_equal(full, ctx.forward(images))
+    assert np.array_equal(ctx.forward(images[2:4]), full[2:4])
+    ctx.set_streams(2)
+    assert np.array_equal(ctx.forward(images), full)
+    ctx.close()
+    with pytest.raises(vithip.VhError):
+        vithip.VitContext(S.CONFIGS["vit_tiny"], dtype=FP8, max_batch=1)   # dim 192 is not a multiple of 128

@@ -284,4 +284,61 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const 
     }
 }
 
+// ---- e4m3 output (fp8 path, fc1): v = gelu(acc + bias) -> 1 byte -----------------------------------------
+// A lane's accumulator quad is 4 consecutive columns = one dword of e4m3.  Staged like the 16-bit form: the
+// wave's 64-column rows are 64 B = 4 chunks of 16 B, chunk c of row r at position c ^ ((r >> 1) & 3); read back
+// 16 B per lane, 4 lanes per row, and stored as whole 64-B row segments.  Ragged tiles store dwords directly.
+template <int EPI, int MI, int NI, int SMI>
+__device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w, int lane,
+                                               bool n_full, bool m_full, char* smem, int wave) {
+    static_assert(NI == 4 && MI % SMI == 0, "64-column wave tile");
+    static_assert(EPI == VH_EPI_BIAS || EPI == VH_EPI_BIAS_GELU, "8-bit output: bias or bias+GELU");
+    const int M = e.M, N = e.N;
+    const int frow = lane & 15, fq = lane >> 4;
+    uint8_t* const out = (uint8_t*)e.out;
+    auto value = [&](const f32x4& a, const f32x4& b) {
+        f32x4 v = a + b;
+        if constexpr (EPI == VH_EPI_BIAS_GELU) v = gelu_poly4(v);
+        return pack4_e4m3(v[0], v[1], v[2], v[3]);
+    };
+    if (n_full) {
+        f32x4 bv[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
+        char* sw = smem + wave * (SMI * 16 * 128);
+        const int rr = lane >> 2, pc = lane & 3;
+#pragma unroll
+        for (int h = 0; h < MI / SMI; ++h) {
+#pragma unroll
+            for (int mi = 0; mi < SMI; ++mi) {
+                const int r = mi * 16 + frow;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    *(uint32_t*)(sw + r * 64 + ((ni ^ ((r >> 1) & 3)) << 4) + fq * 4) = value(acc[h * SMI + mi][ni], bv[ni]);
+            }
+#pragma unroll
+            for (int i = 0; i < SMI; ++i) {
+                const int r = i * 16 + rr;
+                const u32x4 v = *(const u32x4*)(sw + r * 64 + (pc << 4));
+                const int n = n_w + ((pc ^ ((r >> 1) & 3)) << 4);
+                const int m = m_w + h * SMI * 16 + r;
+                if (m < M) __builtin_nontemporal_store(v, (u32x4*)(out + (int64_t)m * N + n));
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = n_w + ni * 16 + fq * 4;
+        if (n >= N) continue;
+        const f32x4 bv = *(const f32x4*)(e.bias + n);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m_w + mi * 16 + frow;
+            if (m < M) *(uint32_t*)(out + (int64_t)m * N + n) = value(acc[mi][ni], bv);
+        }
+    }
+    (void)m_full;
+}
+
 }  // namespace vh

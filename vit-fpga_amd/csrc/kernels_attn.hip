@@ -57,9 +57,9 @@ __device__ __forceinline__ float cross_half_sum(float v) {
     return a + b;
 }
 
-template <typename T, bool PERSIST>
+template <typename T, bool PERSIST, typename TO = T>   // TO: output element (T, or E4M3 on the fp8 path)
 __global__ void __launch_bounds__(512)
-attention_kernel(const typename T::elem* __restrict__ qkv, typename T::elem* __restrict__ out,
+attention_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __restrict__ out,
                  int tokens, int heads, int slabs, int ntiles, int nitems) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
@@ -220,11 +220,11 @@ attention_kernel(const typename T::elem* __restrict__ qkv, typename T::elem* __r
             const float inv = 1.0f / ltot;
             const int q = q0 + l31;
             if (q < tokens) {
-                elem* op = out + ((int64_t)b * tokens + q) * D + h * 64 + 4 * hl;
+                typename TO::elem* op = out + ((int64_t)b * tokens + q) * D + h * 64 + 4 * hl;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    *(vec4*)(op + 8 * rg) = pack4<T>(o0[4 * rg] * inv, o0[4 * rg + 1] * inv, o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
-                    *(vec4*)(op + 32 + 8 * rg) = pack4<T>(o1[4 * rg] * inv, o1[4 * rg + 1] * inv, o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
+                    *(typename TO::vec4*)(op + 8 * rg) = pack4<TO>(o0[4 * rg] * inv, o0[4 * rg + 1] * inv, o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
+                    *(typename TO::vec4*)(op + 32 + 8 * rg) = pack4<TO>(o1[4 * rg] * inv, o1[4 * rg + 1] * inv, o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
                 }
             }
         }
@@ -238,7 +238,7 @@ attention_kernel(const typename T::elem* __restrict__ qkv, typename T::elem* __r
 
 size_t attention_lds_bytes(int tokens) { return (size_t)((tokens + 31) / 32) * 8192; }
 
-template <typename T>
+template <typename T, typename TO = T>
 static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, hipStream_t s) {
     const int ntiles = (tokens + 31) / 32;
     const int nqb = ntiles;
@@ -260,6 +260,18 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     static int want_persist = -1;
     if (want_persist < 0) { const char* e = getenv("VH_ATTN_PERSIST"); want_persist = e ? atoi(e) : 0; }
     const bool persist = want_persist && 2 * one <= 160 * 1024 && nitems > num_cu;
+    if constexpr (!std::is_same<T, TO>::value) {
+        auto k = attention_kernel<T, false, TO>;
+        static size_t lds_max = 0;
+        if (one > lds_max) {
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)one);
+            if (e != hipSuccess) return e;
+            lds_max = one;
+        }
+        hipLaunchKernelGGL(k, dim3(nitems), dim3(nw * 64), one, s, (const typename T::elem*)qkv, (typename TO::elem*)out,
+                           tokens, heads, slabs, ntiles, nitems);
+        return hipGetLastError();
+    } else
     if (persist) {
         const size_t lds = 2 * one;
         auto k = attention_kernel<T, true>;
@@ -291,6 +303,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype,
                             hipStream_t s) {
     if (batch <= 0 || tokens <= 0 || heads <= 0) return hipErrorInvalidValue;
+    if (dtype == VH_DTYPE_FP8) return launch_attn_t<BF16, E4M3>(qkv16, batch, tokens, heads, out16, s);  // bf16 in, e4m3 out
     return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16>(qkv16, batch, tokens, heads, out16, s)
                                   : launch_attn_t<FP16>(qkv16, batch, tokens, heads, out16, s);
 }

@@ -33,6 +33,17 @@
 // of the NEXT tile's K-tile 0 into stage 0, runs the epilogue through 8 KiB-per-wave slices of stage 1, then
 // issues K-tile 1 into stage 1: the next tile's first operands are already in LDS when its loop starts, and no
 // workgroup launch/drain sits between tiles.
+//
+// fp8 form (F8 = true, VH_DTYPE_FP8): A and W are OCP e4m3 bytes, a K-tile is still 128 B per row (128 elements),
+// so the DMA, the LDS image, the swizzle and the hazard table are byte for byte the ones above.  The matrix
+// instruction is v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (twice the cycles of the bf16
+// 16x16x32 form at four times the K: 2x the bf16 rate); lane l carries row l&15 and the 32 k-bytes of group
+// l>>4 (tools/probe_fp8.hip), i.e. chunks 2g and 2g+1 of the 128-B row.  One K-tile is ONE k-step, so the two
+// compute phases split the wave tile by rows instead of by k:
+//      L0: W fragments + X fragments of row blocks 0-3     C0: 16 MFMAs (row blocks 0-3)
+//      L1: X fragments of row blocks 4-7                   C1: 16 MFMAs (row blocks 4-7)
+// (same 512 matrix cycles per phase, same 64 fragment registers).  W carries one fp32 scale per output channel
+// (`aux`), applied to the accumulators before the epilogue; activations are unscaled (vh_common.h, E4M3).
 #include "gemm_epilogue.h"
 #include "vh_kernels.h"
 
@@ -52,16 +63,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {  // bijective on [0, 
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
 }
 
-template <typename T, int EPI, bool PERSIST>
+template <typename T, int EPI, bool PERSIST, bool F8 = false>
 __global__ void __launch_bounds__(512, 2)
-gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W,
+gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                   const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
                   void* __restrict__ out16, float* __restrict__ partials) {
-    using elem = typename T::elem;
     using vec8 = typename T::vec8;
-    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int BM = 256, BN = 256;
+    constexpr int KT_BYTES = 128;                  // one K-tile row: 64 16-bit or 128 8-bit elements
     constexpr int STAGE_BYTES = 65536, W_OFF = 32768;
+    const char* const A = (const char*)Av;
+    const char* const W = (const char*)Wv;
+    const int64_t row_bytes = (int64_t)K * (F8 ? 1 : 2);
     constexpr int MI = 8, NI = 4;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,7 +90,7 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
 
     // ---- DMA: this wave moves 4 x 1 KiB of its group's A half and 4 x 1 KiB of its group's W half -------
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-    const elem *gA[4], *gW[4];
+    const char *gA[4], *gW[4];
     int tile_m = 0, tile_n = 0;
     auto setup_tile = [&](int tt) {
         tile_m = tt / tiles_n;
@@ -87,8 +101,8 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
             int ra = tile_m * BM + r, rw = tile_n * BN + r;
             ra = ra < M ? ra : M - 1;
             rw = rw < N ? rw : N - 1;
-            gA[i] = A + (int64_t)ra * K + lc * 8;
-            gW[i] = W + (int64_t)rw * K + lc * 8;
+            gA[i] = A + ra * row_bytes + lc * 16;
+            gW[i] = W + rw * row_bytes + lc * 16;
         }
     };
     const int dma_off = grp * 16384 + wn * 1024;  // + i * 4096
@@ -96,25 +110,26 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
         char* dst = smem + (kt & 1) * STAGE_BYTES + dma_off;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gA[i] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gA[i] + kt * KT_BYTES),
                                              (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
     };
     auto issue_w = [&](int kt) {
         char* dst = smem + (kt & 1) * STAGE_BYTES + W_OFF + dma_off;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gW[i] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gW[i] + kt * KT_BYTES),
                                              (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
     };
 
     // ---- fragment addresses ----------------------------------------------------------------------------------
     const int frow = lane & 15, fq = lane >> 4;
-    const int off0 = frow * 128 + (((0 | fq) ^ (frow & 7)) << 4);
-    const int off1 = frow * 128 + (((4 | fq) ^ (frow & 7)) << 4);
+    // 16-bit: k-step 0 / 1 = chunk fq / 4+fq; fp8: the lane's 32 k-bytes = chunks 2fq and 2fq+1
+    const int off0 = frow * 128 + (((F8 ? 2 * fq : fq) ^ (frow & 7)) << 4);
+    const int off1 = frow * 128 + (((F8 ? 2 * fq + 1 : 4 | fq) ^ (frow & 7)) << 4);
     const int xbase = grp * 16384;          // rows 128*grp ..
     const int wbase = W_OFF + wn * 8192;    // rows 64*wn ..
 
-    const int nk = K / BK;
+    const int nk = (int)(row_bytes / KT_BYTES);
 
     // ---- prologue of the first tile: K-tiles 0 and 1 ------------------------------------------------------------
     setup_tile(t);
@@ -131,13 +146,65 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        vec8 wf0[NI], wf1[NI], xf[MI];
 
         if (nk > 1) pp_wait_vmcnt<8>();  // K-tile 0 landed (and any earlier stores), K-tile 1 may fly
         else pp_wait_vmcnt<0>();
         pp_barrier();                 // K-tile 0 visible
         if (grp == 1) pp_barrier();   // G1 runs one phase behind
 
+        if constexpr (F8) {
+            i32x8 wf[NI], xf[MI / 2];
+            const int unit = 0x7F7F7F7F;  // E8M0 1.0 for every 32-element block
+            auto ld8 = [&](const char* p) {
+                const u32x4 lo = *(const u32x4*)(p + off0), hi = *(const u32x4*)(p + off1);
+                return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            };
+            for (int kt = 0; kt < nk; ++kt) {
+                const char* st = smem + (kt & 1) * STAGE_BYTES;
+                // ---- L0 ----
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) wf[ni] = ld8(st + wbase + ni * 2048);
+#pragma unroll
+                for (int mi = 0; mi < MI / 2; ++mi) xf[mi] = ld8(st + xbase + mi * 2048);
+                if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                pp_barrier();
+                // ---- C0 ----
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mi = 0; mi < MI / 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf[mi], acc[mi][ni], 0, 0, 0, unit, 0, unit);
+                __builtin_amdgcn_s_setprio(0);
+                pp_barrier();
+                // ---- L1 ----
+#pragma unroll
+                for (int mi = 0; mi < MI / 2; ++mi) xf[mi] = ld8(st + xbase + (MI / 2 + mi) * 2048);
+                if (kt + 2 < nk) {
+                    issue_w(kt + 2);
+                    pp_wait_vmcnt<8>();
+                } else if (kt + 1 < nk) {
+                    pp_wait_vmcnt<4>();
+                } else {
+                    pp_wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                pp_barrier();
+                // ---- C1 ----
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mi = 0; mi < MI / 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[MI / 2 + mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf[mi], acc[MI / 2 + mi][ni], 0, 0, 0, unit, 0, unit);
+                __builtin_amdgcn_s_setprio(0);
+                if (kt + 2 < nk) pp_wait_vmcnt<4>();
+                else pp_wait_vmcnt<0>();
+                pp_barrier();
+            }
+        } else {
+        vec8 wf0[NI], wf1[NI], xf[MI];
         for (int kt = 0; kt < nk; ++kt) {
             const char* st = smem + (kt & 1) * STAGE_BYTES;
             // ---- L0 ------------------------------------------------------------------------------------------------
@@ -183,6 +250,7 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
             else pp_wait_vmcnt<0>();
             pp_barrier();
         }
+        }
         if (grp == 0) pp_barrier();  // G0 waits for G1's last phase: every LDS read of this tile is complete
 
         // ---- tile boundary --------------------------------------------------------------------------------------
@@ -196,7 +264,20 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
             issue_a(0);
         }
         const EpiArgs e{bias, outp, M, N, aux, aux_i, stats, out16, partials};
-        gemm_epilogue<T, EPI, MI, NI, 4, false>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);
+        if constexpr (F8) {
+            // per-output-channel weight scale (`aux`): the lane's 4 consecutive columns of column block ni
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = n_w + ni * 16 + fq * 4;
+                const f32x4 ws = n < N ? *(const f32x4*)(aux + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = acc[mi][ni] * ws;
+            }
+        }
+        if constexpr (F8 && EPI == VH_EPI_BIAS_GELU)
+            gemm_epilogue8<EPI, MI, NI, 4>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);
+        else
+            gemm_epilogue<T, EPI, MI, NI, 4, false>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);
         if (!has_next) break;
         if (nk > 1) {
             pp_barrier();  // every wave is done with its staging slice of stage 1
@@ -207,8 +288,8 @@ gemm_nt_pp_kernel(const typename T::elem* __restrict__ A, const typename T::elem
     }
 }
 
-template <typename T, int EPI>
-hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t s) {
+template <typename T, int EPI, bool F8>
+static hipError_t launch_pp(const GemmArgs& g, bool persistent, hipStream_t s) {
     const int tiles_m = (int)((g.M + 255) / 256), tiles_n = (g.N + 255) / 256;
     constexpr size_t lds = 131072;
     static int num_cu = 0;
@@ -220,28 +301,33 @@ hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t 
     }
     const int ntiles = tiles_m * tiles_n;
     if (persistent) {
-        auto k = gemm_nt_pp_kernel<T, EPI, true>;
+        auto k = gemm_nt_pp_kernel<T, EPI, true, F8>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
-        hipLaunchKernelGGL(k, dim3(ntiles < num_cu ? ntiles : num_cu), dim3(512), lds, s, (const typename T::elem*)g.a,
-                           (const typename T::elem*)g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n,
+        hipLaunchKernelGGL(k, dim3(ntiles < num_cu ? ntiles : num_cu), dim3(512), lds, s, g.a,
+                           g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n,
                            g.stats, g.out16, g.partials);
     } else {
-        auto k = gemm_nt_pp_kernel<T, EPI, false>;
+        auto k = gemm_nt_pp_kernel<T, EPI, false, F8>;
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
-        hipLaunchKernelGGL(k, dim3(ntiles), dim3(512), lds, s, (const typename T::elem*)g.a, (const typename T::elem*)g.w,
+        hipLaunchKernelGGL(k, dim3(ntiles), dim3(512), lds, s, g.a, g.w,
                            g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n, g.stats, g.out16, g.partials);
     }
     return hipGetLastError();
+}
+
+template <typename T, int EPI>
+hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t s) {
+    return launch_pp<T, EPI, false>(g, persistent, s);
 }
 
 #define VH_INST(T)                                                                                     \
@@ -255,5 +341,16 @@ hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t 
     template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_LN>(const GemmArgs&, bool, hipStream_t);
 VH_INST(BF16)
 VH_INST(FP16)
+
+// fp8 operands: 16-bit results are bf16; fc1 writes e4m3 (gemm_epilogue8)
+hipError_t launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
+    switch (g.epilogue) {
+        case VH_EPI_BIAS: return launch_pp<BF16, VH_EPI_BIAS, true>(g, false, s);
+        case VH_EPI_BIAS_GELU: return launch_pp<BF16, VH_EPI_BIAS_GELU, true>(g, false, s);
+        case VH_EPI_BIAS_RESID: return launch_pp<BF16, VH_EPI_BIAS_RESID, true>(g, false, s);
+        case VH_EPI_BIAS_F32: return launch_pp<BF16, VH_EPI_BIAS_F32, true>(g, false, s);
+        default: return hipErrorInvalidValue;
+    }
+}
 
 }  // namespace vh

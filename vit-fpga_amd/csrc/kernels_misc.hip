@@ -70,6 +70,7 @@ static hipError_t ln_t(const float* x, int64_t rows, int dim, int64_t stride, co
 hipError_t launch_layernorm(const float* x, int64_t rows, int dim, int64_t row_stride, const float* gamma,
                             const float* beta, float eps, void* out16, int dtype, hipStream_t s) {
     if (rows <= 0 || dim <= 0 || (dim & 3) || (row_stride & 3)) return hipErrorInvalidValue;
+    if (dtype == VH_DTYPE_FP8) return ln_t<E4M3>(x, rows, dim, row_stride, gamma, beta, eps, out16, s);  // 1 byte / element
     return dtype == VH_DTYPE_BF16 ? ln_t<BF16>(x, rows, dim, row_stride, gamma, beta, eps, out16, s)
                                   : ln_t<FP16>(x, rows, dim, row_stride, gamma, beta, eps, out16, s);
 }
@@ -136,7 +137,8 @@ hipError_t launch_cast(const float* in, void* out16, int64_t n, int dtype, hipSt
     if (n <= 0 || (n & 3)) return hipErrorInvalidValue;
     const int64_t n4 = n / 4;
     const unsigned grid = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    if (dtype == VH_DTYPE_BF16) hipLaunchKernelGGL(cast_kernel<BF16>, dim3(grid), dim3(256), 0, s, in, (BF16::elem*)out16, n4);
+    if (dtype == VH_DTYPE_FP8) hipLaunchKernelGGL(cast_kernel<E4M3>, dim3(grid), dim3(256), 0, s, in, (E4M3::elem*)out16, n4);
+    else if (dtype == VH_DTYPE_BF16) hipLaunchKernelGGL(cast_kernel<BF16>, dim3(grid), dim3(256), 0, s, in, (BF16::elem*)out16, n4);
     else hipLaunchKernelGGL(cast_kernel<FP16>, dim3(grid), dim3(256), 0, s, in, (FP16::elem*)out16, n4);
     return hipGetLastError();
 }
@@ -158,6 +160,39 @@ hipError_t launch_fill(float* out, int64_t n, uint64_t seed, uint32_t tensor_id,
     const unsigned grid = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
     hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, s, out, n, rng_stream(seed, tensor_id), kind,
                        (double)sigma / kIH4Std, offset);
+    return hipGetLastError();
+}
+
+// ---- fp8 weight quantisation: one wave per row -------------------------------------------------------------
+// s0 = amax_r * (1/448) (1 if the row is all zero), q = rne_e4m3(w / s0) (IEEE division: the oracle's quantiser
+// divides too, so both produce the same byte), scale[r] = s0 * post.
+__global__ void __launch_bounds__(256)
+quantize_rows_kernel(const float* __restrict__ w, int rows, int cols, float post, uint8_t* __restrict__ w8,
+                     float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const f32x4* wr = (const f32x4*)(w + (int64_t)r * cols);
+    const int n4 = cols >> 2;
+    float amax = 0.f;
+    for (int c = lane; c < n4; c += 64) {
+        const f32x4 v = wr[c];
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float s0 = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    uint32_t* orow = (uint32_t*)(w8 + (int64_t)r * cols);
+    for (int c = lane; c < n4; c += 64) {
+        const f32x4 v = wr[c];
+        orow[c] = pack4_e4m3(__fdiv_rn(v[0], s0), __fdiv_rn(v[1], s0), __fdiv_rn(v[2], s0), __fdiv_rn(v[3], s0));
+    }
+    if (lane == 0) scale[r] = s0 * post;
+}
+hipError_t launch_quantize_rows(const float* w, int rows, int cols, float post, void* w8, float* scale, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || (cols & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, w, rows, cols, post,
+                       (uint8_t*)w8, scale);
     return hipGetLastError();
 }
 

@@ -63,6 +63,30 @@ __device__ __forceinline__ typename T::vec4 pack4(float a, float b, float c, flo
     return v;
 }
 
+// 8-bit OUTPUT type of the fp8 path (VH_DTYPE_FP8): OCP e4m3fn, no scale, saturating at +-448.
+// v_cvt_pk_fp8_f32 rounds to nearest even but turns |x| > 464 into NaN (tools/probe_fp8.hip), hence the clamp.
+// Only the kernels that PRODUCE a GEMM operand are instantiated on it (LayerNorm, attention output, cast, the
+// fc1 epilogue); the MFMA side of the format lives in kernels_gemm5.hip.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+struct E4M3 {
+    using elem = uint8_t;
+    using vec4 = uint32_t;
+    static constexpr int id = VH_DTYPE_FP8;
+};
+__device__ __forceinline__ uint32_t pack4_e4m3(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+    b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+    c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+    d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+    return (uint32_t)p;
+}
+template <>
+__device__ __forceinline__ uint32_t pack4<E4M3>(float a, float b, float c, float d) {
+    return pack4_e4m3(a, b, c, d);
+}
+
 __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }

@@ -24,6 +24,9 @@ struct GemmArgs {
 
 // every launcher only enqueues on `stream`; returns hipSuccess or the launch error
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t stream);
+// fp8 form (kernels_gemm5.hip): a, w = e4m3 [M,K] / [N,K]; aux = per-output-channel weight scale [N];
+// epilogue BIAS (bf16 out), BIAS_GELU (e4m3 out), BIAS_RESID / BIAS_F32 (fp32 out).  K % 128 == 0, N % 4 == 0.
+hipError_t launch_gemm_fp8(const GemmArgs& g, hipStream_t stream);
 const char* gemm_check(const GemmArgs& g);  // NULL if the shape is supported, else the reason
 int gemm_pick_variant(int64_t M, int N);
 
@@ -40,6 +43,9 @@ hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int bat
 hipError_t launch_cast(const float* in, void* out16, int64_t n, int dtype, hipStream_t stream);
 hipError_t launch_fill(float* out, int64_t n, uint64_t seed, uint32_t tensor_id, int kind,
                        float sigma, float offset, hipStream_t stream);
+// fp8 weight quantisation: w fp32 [rows, cols] -> e4m3 [rows, cols] with scale[r] = post * amax_r / 448 (amax 0 -> post),
+// q = rne_e4m3(w / (amax_r / 448)); `post` folds a constant factor into the scale (the q rows' softmax scale)
+hipError_t launch_quantize_rows(const float* w, int rows, int cols, float post, void* w8, float* scale, hipStream_t stream);
 // weight preparation (fp32 canonical tensors -> compute layout)
 hipError_t launch_pack_qkv(const float* qw, const float* qb, const float* kw, const float* kb,
                            const float* vw, const float* vb, int dim, float q_scale, void* w16,

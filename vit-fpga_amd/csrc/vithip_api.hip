@@ -94,7 +94,8 @@ const char* check_config(const vh_config& c) {
     if (c.dim > 2048) return "dim > 2048 unsupported";
     if (c.layers <= 0) return "layers must be positive";
     if (c.classes <= 0 || c.classes % 4) return "classes must be a positive multiple of 4";
-    if (c.dtype != VH_DTYPE_BF16 && c.dtype != VH_DTYPE_FP16) return "dtype must be VH_DTYPE_BF16 or VH_DTYPE_FP16";
+    if (c.dtype != VH_DTYPE_BF16 && c.dtype != VH_DTYPE_FP16 && c.dtype != VH_DTYPE_FP8) return "dtype must be VH_DTYPE_BF16, VH_DTYPE_FP16 or VH_DTYPE_FP8";
+    if (c.dtype == VH_DTYPE_FP8 && (c.dim % 128 || c.mlp_dim % 128)) return "VH_DTYPE_FP8 needs dim and mlp_dim to be multiples of 128";
     if (c.max_batch <= 0) return "max_batch must be positive";
     if (!(c.ln_eps > 0.f)) return "ln_eps must be positive";
     if (c.reserved != 0) return "reserved must be 0";
@@ -130,6 +131,11 @@ struct vh_ctx {
     void* head16 = nullptr;   // [C, D]
     std::vector<void*> wqkv16, wo16, w1_16, w2_16;
     float* bqkv = nullptr;    // [layers, 3D]
+    // VH_DTYPE_FP8: the four per-layer matrices hold e4m3 bytes (in the same arena) + one fp32 scale per output channel;
+    // everything 16-bit (patch embedding, qkv, head) is bf16
+    bool fp8 = false;
+    int dt16 = VH_DTYPE_BF16;
+    std::vector<float*> sqkv, so, s1, s2;
     // LayerNorm folded into the q|k|v and fc1 GEMMs (dim and mlp_dim multiples of 256):
     bool ln_fold = false;
     float* fold_cd = nullptr; // per layer: cqkv[3D] dqkv[3D] c1[M] d1[M]
@@ -197,8 +203,23 @@ int prepare_weights(vh_ctx* c) {
     const int D = f.dim, M = f.mlp_dim;
     hipStream_t s = c->stream;
     const float* P = c->params;
-    HIPCHK(&c->err, launch_permute_patch(P + L.patch_w, D, f.channels, f.patch_size, c->wp16, f.dtype, s));
-    for (int l = 0; l < f.layers; ++l) {
+    HIPCHK(&c->err, launch_permute_patch(P + L.patch_w, D, f.channels, f.patch_size, c->wp16, c->dt16, s));
+    for (int l = 0; l < f.layers && c->fp8; ++l) {
+        const LayerOff& o = L.layer[l];
+        // bias [bq/8 ; bk ; bv] from the 16-bit packer (its 16-bit matrix is overwritten right after), then
+        // e4m3 rows + scales; the softmax scale 1/8 goes into the q rows' scales (a power of two: exact)
+        HIPCHK(&c->err, launch_pack_qkv(P + o.qw, P + o.qb, P + o.kw, P + o.kb, P + o.vw, P + o.vb, D, 0.125f,
+                                        c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, c->dt16, s));
+        char* wq = (char*)c->wqkv16[l];
+        const size_t dd = (size_t)D * D;
+        HIPCHK(&c->err, launch_quantize_rows(P + o.qw, D, D, 0.125f, wq, c->sqkv[l], s));
+        HIPCHK(&c->err, launch_quantize_rows(P + o.kw, D, D, 1.0f, wq + dd, c->sqkv[l] + D, s));
+        HIPCHK(&c->err, launch_quantize_rows(P + o.vw, D, D, 1.0f, wq + 2 * dd, c->sqkv[l] + 2 * D, s));
+        HIPCHK(&c->err, launch_quantize_rows(P + o.ow, D, D, 1.0f, c->wo16[l], c->so[l], s));
+        HIPCHK(&c->err, launch_quantize_rows(P + o.f1w, M, D, 1.0f, c->w1_16[l], c->s1[l], s));
+        HIPCHK(&c->err, launch_quantize_rows(P + o.f2w, D, M, 1.0f, c->w2_16[l], c->s2[l], s));
+    }
+    for (int l = 0; l < f.layers && !c->fp8; ++l) {
         const LayerOff& o = L.layer[l];
         if (c->ln_fold) {
             // W' = gamma o W (q rows also carry the softmax scale), c = row sums of W', d = beta.W + b
@@ -217,7 +238,7 @@ int prepare_weights(vh_ctx* c) {
         HIPCHK(&c->err, launch_cast(P + o.ow, c->wo16[l], (int64_t)D * D, f.dtype, s));
         HIPCHK(&c->err, launch_cast(P + o.f2w, c->w2_16[l], (int64_t)D * M, f.dtype, s));
     }
-    HIPCHK(&c->err, launch_cast(P + L.headw, c->head16, (int64_t)f.classes * D, f.dtype, s));
+    HIPCHK(&c->err, launch_cast(P + L.headw, c->head16, (int64_t)f.classes * D, c->dt16, s));
     HIPCHK(&c->err, hipStreamSynchronize(s));
     c->weights_ready = true;
     return VH_OK;
@@ -243,12 +264,13 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     const int64_t rows = (int64_t)batch * T;
     const float* P = c->params;
     // this part's slices of the arena
-    const size_t r0 = (size_t)img0 * T, esz = 2;
+    const size_t r0 = (size_t)img0 * T, esz = 2, esz_op = c->fp8 ? 1 : 2;  // esz_op: GEMM A-operand element
+    const int dt16 = c->dt16;
     float* const x = c->x + r0 * D;
-    char* const xn16 = (char*)c->xn16 + r0 * D * esz;
+    char* const xn16 = (char*)c->xn16 + r0 * D * esz_op;
     char* const qkv16 = (char*)c->qkv16 + r0 * 3 * D * esz;
-    char* const att16 = (char*)c->att16 + r0 * D * esz;
-    char* const h16 = (char*)c->h16 + r0 * M * esz;
+    char* const att16 = (char*)c->att16 + r0 * D * esz_op;
+    char* const h16 = (char*)c->h16 + r0 * M * esz_op;
     char* const col16 = (char*)c->col16 + (size_t)img0 * L.NP * L.KP * esz;
     char* const clsn16 = (char*)c->clsn16 + (size_t)img0 * D * esz;
     auto mark = [&](int stage) -> int {
@@ -261,7 +283,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     };
     auto gemm = [&](const void* a, const void* w, const float* bias, void* out, int64_t Mr, int N, int K, int epi,
                     const float* aux, int aux_i) {
-        GemmArgs g{a, w, bias, out, Mr, N, K, epi, aux, aux_i, f.dtype, 0};
+        GemmArgs g{a, w, bias, out, Mr, N, K, epi, aux, aux_i, dt16, 0};
         g.stats = c->stats;        // read by LNFOLD*, ignored otherwise
         g.out16 = xn16;            // written by RESID_LN
         g.partials = c->partials;
@@ -280,7 +302,13 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     };
     int rc;
     if ((rc = mark(-1))) return rc;
-    HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, col16, f.dtype, s));
+    // e4m3 x e4m3 GEMM of the fp8 path: `scale` = per-output-channel weight scales
+    auto gemm8 = [&](const void* a, const void* w, const float* bias, const float* scale, void* out, int64_t Mr, int N,
+                     int K, int epi) {
+        GemmArgs g{a, w, bias, out, Mr, N, K, epi, scale, 0, VH_DTYPE_FP8, 0};
+        return launch_gemm_fp8(g, s);
+    };
+    HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, col16, dt16, s));
     if ((rc = mark(ST_IM2COL))) return rc;
     HIPCHK(&c->err, gemm(col16, c->wp16, P + L.patch_b, x, (int64_t)batch * L.NP, D, L.KP, VH_EPI_PATCH, P + L.pos, L.NP));
     if ((rc = mark(ST_PATCH))) return rc;
@@ -289,7 +317,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
     if (c->ln_fold && nl > 0) {
         // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
-        HIPCHK(&c->err, launch_rowstats_cast(x, rows, D, f.ln_eps, xn16, c->stats, f.dtype, s));
+        HIPCHK(&c->err, launch_rowstats_cast(x, rows, D, f.ln_eps, xn16, c->stats, dt16, s));
         if ((rc = mark(ST_LNSTATS))) return rc;
     }
     for (int l = 0; l < nl && c->ln_fold; ++l) {
@@ -301,7 +329,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, f.dtype, s));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, dt16, s));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
@@ -323,10 +351,41 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
             if ((rc = mark(ST_LNSTATS))) return rc;
         }
     }
-    for (int l = 0; l < nl && !c->ln_fold; ++l) {
+    for (int l = 0; l < nl && c->fp8; ++l) {
         const LayerOff& o = L.layer[l];
         if ((rc = tmark(ST_LN))) return rc;
-        HIPCHK(&c->err, launch_layernorm(x, rows, D, D, P + o.ln1w, P + o.ln1b, f.ln_eps, xn16, f.dtype, s));
+        HIPCHK(&c->err, launch_layernorm(x, rows, D, D, P + o.ln1w, P + o.ln1b, f.ln_eps, xn16, VH_DTYPE_FP8, s));
+        if ((rc = tmark(ST_LN))) return rc;
+        if ((rc = mark(ST_LN))) return rc;
+        if ((rc = tmark(ST_QKV))) return rc;
+        HIPCHK(&c->err, gemm8(xn16, c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, c->sqkv[l], qkv16, rows, 3 * D, D, VH_EPI_BIAS));
+        if ((rc = tmark(ST_QKV))) return rc;
+        if ((rc = mark(ST_QKV))) return rc;
+        if ((rc = tmark(ST_ATTN))) return rc;
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, VH_DTYPE_FP8, s));
+        if ((rc = tmark(ST_ATTN))) return rc;
+        if ((rc = mark(ST_ATTN))) return rc;
+        if ((rc = tmark(ST_PROJ))) return rc;
+        HIPCHK(&c->err, gemm8(att16, c->wo16[l], P + o.ob, c->so[l], x, rows, D, D, VH_EPI_BIAS_RESID));
+        if ((rc = tmark(ST_PROJ))) return rc;
+        if ((rc = mark(ST_PROJ))) return rc;
+        if ((rc = tmark(ST_LN))) return rc;
+        HIPCHK(&c->err, launch_layernorm(x, rows, D, D, P + o.ln2w, P + o.ln2b, f.ln_eps, xn16, VH_DTYPE_FP8, s));
+        if ((rc = tmark(ST_LN))) return rc;
+        if ((rc = mark(ST_LN))) return rc;
+        if ((rc = tmark(ST_FC1))) return rc;
+        HIPCHK(&c->err, gemm8(xn16, c->w1_16[l], P + o.f1b, c->s1[l], h16, rows, M, D, VH_EPI_BIAS_GELU));
+        if ((rc = tmark(ST_FC1))) return rc;
+        if ((rc = mark(ST_FC1))) return rc;
+        if ((rc = tmark(ST_FC2))) return rc;
+        HIPCHK(&c->err, gemm8(h16, c->w2_16[l], P + o.f2b, c->s2[l], x, rows, D, M, VH_EPI_BIAS_RESID));
+        if ((rc = tmark(ST_FC2))) return rc;
+        if ((rc = mark(ST_FC2))) return rc;
+    }
+    for (int l = 0; l < nl && !c->ln_fold && !c->fp8; ++l) {
+        const LayerOff& o = L.layer[l];
+        if ((rc = tmark(ST_LN))) return rc;
+        HIPCHK(&c->err, launch_layernorm(x, rows, D, D, P + o.ln1w, P + o.ln1b, f.ln_eps, xn16, dt16, s));
         if ((rc = tmark(ST_LN))) return rc;
         if ((rc = mark(ST_LN))) return rc;
         if ((rc = tmark(ST_QKV))) return rc;
@@ -334,7 +393,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, f.dtype, s));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, dt16, s));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
@@ -342,7 +401,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
         if ((rc = tmark(ST_LN))) return rc;
-        HIPCHK(&c->err, launch_layernorm(x, rows, D, D, P + o.ln2w, P + o.ln2b, f.ln_eps, xn16, f.dtype, s));
+        HIPCHK(&c->err, launch_layernorm(x, rows, D, D, P + o.ln2w, P + o.ln2b, f.ln_eps, xn16, dt16, s));
         if ((rc = tmark(ST_LN))) return rc;
         if ((rc = mark(ST_LN))) return rc;
         if ((rc = tmark(ST_FC1))) return rc;
@@ -354,7 +413,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
     }
-    HIPCHK(&c->err, launch_layernorm(x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn16, f.dtype, s));
+    HIPCHK(&c->err, launch_layernorm(x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn16, dt16, s));
     if ((rc = mark(ST_LNF))) return rc;
     HIPCHK(&c->err, gemm(clsn16, c->head16, P + L.headb, logits, batch, f.classes, D, VH_EPI_BIAS_F32, nullptr, 0));
     if ((rc = mark(ST_HEAD))) return rc;
@@ -509,14 +568,23 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         // 2.3 ms more than the plain ones -> 24.7 ms vs 24.4 ms per step.  Kept for shapes where it pays.
         c->ln_fold = (cfg->dim % 256 == 0) && (cfg->mlp_dim % 256 == 0) && (e && e[0] == '1');
     }
+    c->fp8 = cfg->dtype == VH_DTYPE_FP8;
+    c->dt16 = c->fp8 ? VH_DTYPE_BF16 : cfg->dtype;
+    if (c->fp8) c->ln_fold = false;
     const size_t o_cd = w16_bytes;
     w16_bytes += align_up((size_t)cfg->layers * (6 * D + 2 * M) * 4, 256);
+    const size_t o_sc = w16_bytes, sc_per_layer = 5 * D + M;  // fp8: scales of q|k|v (3D), o (D), fc1 (M), fc2 (D)
+    if (c->fp8) w16_bytes += align_up((size_t)cfg->layers * sc_per_layer * 4, 256);
     CK(hipMalloc((void**)&c->w16, w16_bytes));
     c->wp16 = c->w16 + o_wp; c->head16 = c->w16 + o_head; c->bqkv = (float*)(c->w16 + o_bqkv);
     c->fold_cd = (float*)(c->w16 + o_cd);
     for (int l = 0; l < cfg->layers; ++l) {
         c->wqkv16.push_back(c->w16 + o_qkv[l]); c->wo16.push_back(c->w16 + o_o[l]);
         c->w1_16.push_back(c->w16 + o_1[l]); c->w2_16.push_back(c->w16 + o_2[l]);
+        if (c->fp8) {
+            float* sc = (float*)(c->w16 + o_sc) + (size_t)l * sc_per_layer;
+            c->sqkv.push_back(sc); c->so.push_back(sc + 3 * D); c->s1.push_back(sc + 4 * D); c->s2.push_back(sc + 4 * D + M);
+        }
     }
     // activation arena
     size_t a = 0;
@@ -918,7 +986,7 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
         std::vector<uint16_t> tmp(n);
         HIPCHK(&c->err, hipMemcpy(tmp.data(), c->clsn16, n * 2, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) {
-            if (c->cfg.dtype == VH_DTYPE_BF16) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&host_out[i], &u, 4); }
+            if (c->dt16 == VH_DTYPE_BF16) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&host_out[i], &u, 4); }
             else { _Float16 hval; memcpy(&hval, &tmp[i], 2); host_out[i] = (float)hval; }
         }
         return VH_OK;
@@ -940,6 +1008,24 @@ int vh_op_gemm(const void* a, const void* w, const float* bias, void* out, int64
     GemmArgs g{a, w, bias, out, M, N, K, epi, aux, aux_i, dtype, variant};
     if (const char* why = gemm_check(g)) return fail(nullptr, VH_ERR_INVALID, "%s", why);
     OPCHK(launch_gemm(g, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_gemm_fp8(const void* a8, const void* w8, const float* w_scale, const float* bias, void* out, int64_t M, int N, int K,
+                   int epi, void* stream) {
+    if (!a8 || !w8 || !w_scale || !bias || !out) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 4) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: need K %% 128 == 0 and N %% 4 == 0");
+    if (M > 0x7FFFFFFF / 2) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: M too large");
+    if (epi != VH_EPI_BIAS && epi != VH_EPI_BIAS_GELU && epi != VH_EPI_BIAS_RESID && epi != VH_EPI_BIAS_F32)
+        return fail(nullptr, VH_ERR_UNSUPPORTED, "gemm_fp8: epilogue %d not available", epi);
+    GemmArgs g{a8, w8, bias, out, M, N, K, epi, w_scale, 0, VH_DTYPE_FP8, 0};
+    OPCHK(launch_gemm_fp8(g, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_quantize_rows(const float* w, int rows, int cols, float post_scale, void* w8, float* scale, void* stream) {
+    if (!w || !w8 || !scale || rows <= 0 || cols <= 0 || cols % 4) return fail(nullptr, VH_ERR_INVALID, "quantize_rows: bad argument");
+    OPCHK(launch_quantize_rows(w, rows, cols, post_scale, w8, scale, (hipStream_t)stream));
     OPCHK(hipStreamSynchronize((hipStream_t)stream));
     return VH_OK;
 }

@@ -14,7 +14,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.path.join(PKG_ROOT, "libvithip.so")
 
-DTYPE_BF16, DTYPE_FP16 = 0, 1
+DTYPE_BF16, DTYPE_FP16, DTYPE_FP8 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH, EPI_LNFOLD, EPI_LNFOLD_GELU, EPI_RESID_LN = range(8)
 ACT_IDENTITY, ACT_RELU2, ACT_RELU, ACT_HARDTANH, ACT_GELU = range(5)
 
@@ -78,6 +78,8 @@ SYMBOLS = {
     "vh_debug_read": (_i, [_vp, _i, _vp, _sz]),
     "vh_debug_set_layers": (_i, [_vp, _i]),
     "vh_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "vh_op_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "vh_op_quantize_rows": (_i, [_vp, _i, _i, C.c_float, _vp, _vp, _vp]),
     "vh_op_gemm_ex": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "vh_op_rowstats_cast": (_i, [_vp, _i64, _i, _f, _vp, _vp, _i, _vp]),
     "vh_op_finalize_stats": (_i, [_vp, _i, _i64, _i, _f, _vp, _vp]),
@@ -361,6 +363,27 @@ class MlpContext:
 # ---- operator-level wrappers (device pointers in, nothing hidden) ------------------------------------
 def op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, dtype, aux_ptr=None, aux_i=0, variant=0):
     _check(lib().vh_op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, aux_ptr, aux_i, dtype, variant, None))
+
+
+def op_gemm_fp8(a8_ptr, w8_ptr, scale_ptr, bias_ptr, out_ptr, M, N, K, epilogue):
+    _check(lib().vh_op_gemm_fp8(a8_ptr, w8_ptr, scale_ptr, bias_ptr, out_ptr, M, N, K, epilogue, None))
+
+
+def op_quantize_rows(w_ptr, rows, cols, post_scale, w8_ptr, scale_ptr):
+    _check(lib().vh_op_quantize_rows(w_ptr, rows, cols, post_scale, w8_ptr, scale_ptr, None))
+
+
+# ---- OCP e4m3fn on the host (table-driven; used to build / read fp8 operator operands in tests) ----
+def e4m3_table():
+    b = np.arange(256, dtype=np.uint32)
+    e, m = (b >> 3) & 15, b & 7
+    v = np.where(e == 0, m * 2.0 ** -9, (1 + m / 8.0) * 2.0 ** (e.astype(np.float64) - 7))
+    v = np.where((e == 15) & (m == 7), np.nan, v)
+    return np.where(b >> 7 == 1, -v, v).astype(np.float32)
+
+
+def from_e4m3(b):
+    return e4m3_table()[np.ascontiguousarray(b, dtype=np.uint8)]
 
 
 def op_gemm_ex(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, dtype, aux_ptr=None, aux_i=0, stats_ptr=None,
