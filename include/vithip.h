@@ -115,6 +115,16 @@ int vh_init_weights_seeded(vh_ctx* ctx, uint64_t seed);
 int vh_export_weights(vh_ctx* ctx, void* host_blob, size_t nbytes);
 int vh_export_weights_device(vh_ctx* ctx, void* dev_blob, size_t nbytes);
 
+/* Weight blob on disk (the reference's own attempt at reading weights back, get_net_data
+ * netFPGA.cpp:206-237, is a broken TODO and it has no file format).  The file is the canonical blob byte for
+ * byte, plus an FNV-1a-64 checksum of the parameter bytes in header words that memory blobs leave zero.
+ *   vh_blob_file_config: host only (no device needed) -- validates magic / shape / file length and fills the model
+ *                        fields of *cfg (dtype = VH_DTYPE_BF16, max_batch = 1: set what you need before vh_create);
+ *   vh_save_weights_file: writes <path>.tmp then renames; vh_load_weights_file: verifies length, shape, checksum. */
+int vh_blob_file_config(const char* path, vh_config* cfg);
+int vh_save_weights_file(vh_ctx* ctx, const char* path);
+int vh_load_weights_file(vh_ctx* ctx, const char* path);
+
 /* The hot path.  Replaces launch_forward's device section (netFPGA.cpp:262-284):
  * in  = batch x image x image x channels fp32, NHWC, host memory;
  * out = batch x classes fp32 logits, host memory.  Synchronous, like the blocking read. */

@@ -148,6 +148,17 @@ static void gpu_checks()
     CHECK(r1.size() == 40 && std::equal(r1.begin(), r1.end(), got2.begin()));
     CHECK(seeded.collect_forward().empty());
     CHECK(seeded.launch_forward(img) == got2);               // the synchronous call still works next to the pipeline
+
+    // ---- weights on disk: save, re-create from the file alone, same logits ----
+    const char *path = "/tmp/test_net_hip.vhblob";
+    seeded.save_weights(path);
+    hip::net_hip loaded = hip::net_hip::from_file(path, VH_DTYPE_FP16);
+    CHECK(loaded.is_vit() && loaded.n_ins == 64 * 64 * 3 && !loaded.device_init);
+    CHECK(loaded.launch_forward(img) == got2);
+    bool threw = false;
+    try { hip::net_hip::from_file("/tmp/does_not_exist.vhblob", VH_DTYPE_FP16); } catch (const std::exception &) { threw = true; }
+    CHECK(threw);
+    remove(path);
 }
 
 int main(int argc, char **argv)

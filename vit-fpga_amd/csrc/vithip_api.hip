@@ -46,9 +46,17 @@ struct BlobHeader {
     char magic[8];
     int32_t image_size, patch_size, channels, dim, heads, mlp_dim, layers, classes;
     float ln_eps;
-    uint32_t pad[5];
+    // on-disk files only (vh_save_weights_file): FNV-1a 64 of the parameter bytes, flags bit 0 = checksum present.
+    // Blobs built in memory leave all five words 0.
+    uint32_t sum_lo, sum_hi, flags, pad[2];
 };
 static_assert(sizeof(BlobHeader) == 64, "blob header is 64 bytes");
+
+uint64_t fnv1a64(const void* data, size_t n, uint64_t h = 0xCBF29CE484222325ull) {
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001B3ull; }
+    return h;
+}
 
 struct LayerOff {  // offsets in floats from the start of the parameter region
     size_t ln1w, ln1b, qw, qb, kw, kb, vw, vb, ow, ob, ln2w, ln2b, f1w, f1b, f2w, f2b;
@@ -706,6 +714,78 @@ int vh_export_weights(vh_ctx* c, void* host_blob, size_t nbytes) {
     HIPCHK(&c->err, hipSetDevice(c->device));
     HIPCHK(&c->err, hipMemcpy(host_blob, c->blob, need, hipMemcpyDeviceToHost));
     return VH_OK;
+}
+
+// ---- weight blob on disk ---------------------------------------------------------------------
+// The file IS the canonical blob (64-byte header + fp32 tensors in the fixed order of make_layout), with a
+// checksum of the parameter bytes in the header words a memory blob leaves zero.  It is what vh_load_weights
+// takes, what vh_export_weights returns and what the multi-GPU path broadcasts.
+int vh_blob_file_config(const char* path, vh_config* cfg) {
+    if (!path || !cfg) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(nullptr, VH_ERR_INVALID, "cannot open %s", path);
+    BlobHeader h;
+    const size_t got = fread(&h, 1, sizeof h, f);
+    long long fsize = -1;
+    if (fseek(f, 0, SEEK_END) == 0) fsize = ftell(f);
+    fclose(f);
+    if (got != sizeof h || memcmp(h.magic, "VHBLOB1", 8) != 0) return fail(nullptr, VH_ERR_INVALID, "%s: not a VHBLOB1 file", path);
+    vh_config c;
+    memset(&c, 0, sizeof c);
+    c.image_size = h.image_size; c.patch_size = h.patch_size; c.channels = h.channels; c.dim = h.dim; c.heads = h.heads;
+    c.mlp_dim = h.mlp_dim; c.layers = h.layers; c.classes = h.classes; c.ln_eps = h.ln_eps;
+    c.dtype = VH_DTYPE_BF16; c.max_batch = 1;
+    if (const char* why = check_config(c)) return fail(nullptr, VH_ERR_INVALID, "%s: header describes an unsupported model (%s)", path, why);
+    const size_t need = sizeof(BlobHeader) + 4 * make_layout(c).total;
+    if (fsize != (long long)need) return fail(nullptr, VH_ERR_INVALID, "%s: %lld bytes, the header implies %zu", path, fsize, need);
+    *cfg = c;
+    return VH_OK;
+}
+
+int vh_save_weights_file(vh_ctx* c, const char* path) {
+    if (!c || !path) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (!c->weights_ready) return fail(&c->err, VH_ERR_STATE, "no weights loaded");
+    const size_t need = sizeof(BlobHeader) + 4 * c->L.total;
+    std::vector<char> buf(need);
+    int rc = vh_export_weights(c, buf.data(), need);
+    if (rc) return rc;
+    BlobHeader h;
+    memcpy(&h, buf.data(), sizeof h);
+    const uint64_t sum = fnv1a64(buf.data() + sizeof h, need - sizeof h);
+    h.sum_lo = (uint32_t)sum; h.sum_hi = (uint32_t)(sum >> 32); h.flags = 1; h.pad[0] = h.pad[1] = 0;
+    memcpy(buf.data(), &h, sizeof h);
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(&c->err, VH_ERR_INVALID, "cannot create %s", tmp.c_str());
+    const size_t put = fwrite(buf.data(), 1, need, f);
+    const int bad = fclose(f);
+    if (put != need || bad) { remove(tmp.c_str()); return fail(&c->err, VH_ERR_INVALID, "short write to %s", tmp.c_str()); }
+    if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(&c->err, VH_ERR_INVALID, "cannot rename %s to %s", tmp.c_str(), path); }
+    return VH_OK;
+}
+
+int vh_load_weights_file(vh_ctx* c, const char* path) {
+    if (!c || !path) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
+    const size_t need = sizeof(BlobHeader) + 4 * c->L.total;
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(&c->err, VH_ERR_INVALID, "cannot open %s", path);
+    std::vector<char> buf(need + 1);
+    const size_t got = fread(buf.data(), 1, need + 1, f);
+    fclose(f);
+    if (got != need) return fail(&c->err, VH_ERR_INVALID, "%s holds %s%zu bytes, this model's blob is %zu", path, got > need ? "more than " : "", got > need ? need : got, need);
+    BlobHeader h;
+    memcpy(&h, buf.data(), sizeof h);
+    int rc = check_blob_header(c, h);
+    if (rc) return rc;
+    if (h.flags & 1) {
+        const uint64_t sum = fnv1a64(buf.data() + sizeof h, need - sizeof h);
+        if ((uint32_t)sum != h.sum_lo || (uint32_t)(sum >> 32) != h.sum_hi)
+            return fail(&c->err, VH_ERR_INVALID, "%s: checksum mismatch (file damaged)", path);
+    }
+    // the resident blob is the memory form: checksum words cleared, so export == what make_blob-style writers produce
+    h.sum_lo = h.sum_hi = h.flags = 0;
+    memcpy(buf.data(), &h, sizeof h);
+    return vh_load_weights(c, buf.data(), need);
 }
 
 int vh_export_weights_device(vh_ctx* c, void* dev_blob, size_t nbytes) {

@@ -256,6 +256,36 @@ namespace hip
         device_init = true;
     }
 
+    // ---- weights on disk (ViT mode) ----
+    net_hip net_hip::from_file(const char *blob_path, int vh_dtype, int device_index)
+    {
+        vh_config c;
+        if (vh_blob_file_config(blob_path, &c) != VH_OK)
+            throw runtime_error(string("net_hip::from_file: ") + vh_last_error(nullptr));
+        c.dtype = vh_dtype;
+        FILE *f = fopen(blob_path, "rb");
+        if (!f)
+            throw runtime_error(string("net_hip::from_file: cannot open ") + blob_path);
+        string bytes(vh_weight_blob_bytes(&c), '\0');
+        const size_t got = fread(&bytes[0], 1, bytes.size(), f);
+        fclose(f);
+        if (got != bytes.size())
+            throw runtime_error(string("net_hip::from_file: short read of ") + blob_path);
+        // memory form of the blob: the file's checksum words are cleared (vh_load_weights_file verifies them; here the
+        // length and header were validated by vh_blob_file_config)
+        memset(&bytes[44], 0, 20);
+        return net_hip(c, bytes.data(), bytes.size(), device_index);
+    }
+
+    void net_hip::save_weights(const char *blob_path)
+    {
+        if (!vit_mode)
+            die("save_weights", "only available in ViT mode (MLP mode: get_net_data())");
+        ensure_device(1);
+        if (vh_save_weights_file(vit, blob_path) != VH_OK)
+            die("vh_save_weights_file", vh_last_error(vit));
+    }
+
     // ---- pipelined forward (ViT mode) ----
     void net_hip::set_pipeline(int slots, int max_batch_per_slot)
     {

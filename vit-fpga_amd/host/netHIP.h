@@ -94,6 +94,10 @@ namespace hip
         // ViT mode, pipelined: the shape of filter_image/get_filtered_image (netFPGA.cpp:292-365) applied to
         // launch_forward.  submit_forward returns false when every slot is in flight ("PILA LLENA"),
         // collect_forward returns an empty vector when nothing is ("PILA VACIA"); results come back in FIFO order.
+        // ViT mode, weights on disk: the canonical blob as a file (vithip.h, vh_*_weights_file).  from_file reads the
+        // model shape from the file's header (host only; the device is still touched lazily by the first forward).
+        static net_hip from_file(const char *blob_path, int vh_dtype, int device_index = 0);
+        void save_weights(const char *blob_path);
         void set_pipeline(int slots, int max_batch_per_slot);
         bool submit_forward(const std::vector<DATA_TYPE> &inputs);
         std::vector<DATA_TYPE> collect_forward();

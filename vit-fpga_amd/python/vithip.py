@@ -65,6 +65,9 @@ SYMBOLS = {
     "vh_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double)]),
     "vh_profile_forward": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_double), _i, _pi]),
     "vh_stage_name": (C.c_char_p, [_i]),
+    "vh_blob_file_config": (_i, [C.c_char_p, C.POINTER(Config)]),
+    "vh_save_weights_file": (_i, [_vp, C.c_char_p]),
+    "vh_load_weights_file": (_i, [_vp, C.c_char_p]),
     "vh_ring_create": (_i, [_vp, _i, _i]),
     "vh_ring_destroy": (_i, [_vp]),
     "vh_ring_free_slots": (_i, [_vp, _pi]),
@@ -127,6 +130,13 @@ def device_count():
     n = C.c_int(0)
     rc = lib().vh_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+def blob_file_config(path):
+    """Model shape stored in a VHBLOB1 file (host only) -> dict usable as `cfg`."""
+    c = Config()
+    _check(lib().vh_blob_file_config(os.fsencode(path), C.byref(c)))
+    return {k: getattr(c, k) for k in ("image_size", "patch_size", "channels", "dim", "heads", "mlp_dim", "layers", "classes")}, c.ln_eps
 
 
 def make_config(cfg, dtype=DTYPE_BF16, max_batch=1, ln_eps=1e-6):
@@ -229,6 +239,12 @@ class VitContext:
 
     def export_weights_device(self, ptr, nbytes):
         _check(lib().vh_export_weights_device(self.h, ptr, nbytes), self.h)
+
+    def save_weights_file(self, path):
+        _check(lib().vh_save_weights_file(self.h, os.fsencode(path)), self.h)
+
+    def load_weights_file(self, path):
+        _check(lib().vh_load_weights_file(self.h, os.fsencode(path)), self.h)
 
     def forward(self, images):
         """images: [B, H, W, C] fp32 (host).  Returns [B, classes] fp32 logits."""
