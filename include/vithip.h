@@ -255,6 +255,22 @@ int vh_op_fill(float* out_dev, int64_t n, uint64_t seed, uint32_t tensor_id, int
 int vh_bench_gemm(int device, int64_t M, int N, int K, int epilogue, int dtype, int variant, int iters,
                   double* avg_ms);
 
+/* ---- filter_image pipeline -------------------------------------------------------------------
+ * The reference's second device entry: single-channel 8-bit frames (1080 x 1920, defines.h:31-38) pushed through
+ * a kernel `image_process` with a 24-slot ring of in-flight frames (netFPGA.cpp:47-56, 292-365).  That kernel's
+ * source and bitstream are absent, so WHAT it computed is unknown; the ring mechanics are reproduced and the
+ * arithmetic is a documented choice: a 3x3 filter with replicated borders, integer arithmetic, bit-exact against
+ * oracle_filter3x3.  Frames are `height * width` bytes, row-major. */
+#define VH_FILTER_BLUR3 0   /* (1 2 1 / 2 4 2 / 1 2 1) / 16, rounded half up */
+#define VH_FILTER_SOBEL3 1  /* min(255, |gx| + |gy|) */
+typedef struct vh_filter vh_filter;
+int vh_filter_create(int device, int height, int width, int slots, int kind, vh_filter** out);
+int vh_filter_destroy(vh_filter* f);
+int vh_filter_free_slots(const vh_filter* f, int* n);
+int vh_filter_submit(vh_filter* f, const uint8_t* frame);   /* VH_ERR_RING_FULL when every slot is in flight */
+int vh_filter_collect(vh_filter* f, uint8_t* frame);        /* oldest frame; VH_ERR_RING_EMPTY when none */
+const char* vh_filter_last_error(const vh_filter* f);
+
 /* ---- MLP mode: the reference's actual launch_forward semantics -------------------------- */
 /* y_l = act(W_l y_{l-1} + b_l), weights row-major [n_out, n_in] per layer, layers and biases
  * concatenated exactly as the ctor flattens them (netFPGA.cpp:68-76, 91-106); kernel

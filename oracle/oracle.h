@@ -85,6 +85,9 @@ void oracle_im2col(const float* in_nhwc, int batch, int image, int patch, int ch
 void oracle_round_bf16(float* x, int64_t n);
 void oracle_round_fp16(float* x, int64_t n);
 
+/* ---- filter_image (3x3 filter on 8-bit frames; the build's definition, see vit_oracle.c) ---- */
+void oracle_filter3x3(const uint8_t* in, uint8_t* out, int h, int w, int kind);
+
 /* ---- MLP mode (the reference's real launch_forward semantics) ---------------------------- */
 /* activation codes = include/vithip.h VH_ACT_* */
 int oracle_mlp_forward(int n_ins, int n_layers, const int* n_p_l, const float* params,

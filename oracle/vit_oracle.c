@@ -481,6 +481,33 @@ static int vit_forward_impl(const oracle_vit_config* c, const void* blob, const 
     return 0;
 }
 
+/* 3x3 filter on an 8-bit frame, replicated borders (include/vithip.h, vh_filter_*): kind 0 = binomial blur
+ * (1 2 1 / 2 4 2 / 1 2 1, +8 >> 4), kind 1 = Sobel |gx| + |gy| saturated.  The reference's `image_process`
+ * kernel is absent (netFPGA.cpp:305), so this is the build's definition, not the reference's: PARITY UNPINNED. */
+void oracle_filter3x3(const uint8_t* in, uint8_t* out, int h, int w, int kind) {
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int p[3][3];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    int yy = y + r - 1, xx = x + c - 1;
+                    yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+                    xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+                    p[r][c] = in[(size_t)yy * w + xx];
+                }
+            int v;
+            if (kind == 0) {
+                v = (p[0][0] + 2 * p[0][1] + p[0][2] + 2 * p[1][0] + 4 * p[1][1] + 2 * p[1][2] + p[2][0] + 2 * p[2][1] + p[2][2] + 8) >> 4;
+            } else {
+                const int gx = (p[0][2] + 2 * p[1][2] + p[2][2]) - (p[0][0] + 2 * p[1][0] + p[2][0]);
+                const int gy = (p[2][0] + 2 * p[2][1] + p[2][2]) - (p[0][0] + 2 * p[0][1] + p[0][2]);
+                v = abs(gx) + abs(gy);
+                if (v > 255) v = 255;
+            }
+            out[(size_t)y * w + x] = (uint8_t)v;
+        }
+}
+
 int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float* in,
                        int batch, float* logits, float* hidden, int n_layers_run, int threads) {
     return vit_forward_impl(c, blob, in, batch, logits, hidden, n_layers_run, threads, 0);

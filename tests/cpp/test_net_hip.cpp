@@ -159,6 +159,23 @@ static void gpu_checks()
     try { hip::net_hip::from_file("/tmp/does_not_exist.vhblob", VH_DTYPE_FP16); } catch (const std::exception &) { threw = true; }
     CHECK(threw);
     remove(path);
+
+    // ---- filter_image / get_filtered_image: 24 frames in flight, the 25th is dropped, FIFO results ----
+    net::image_set fs;
+    fs.original_x_pos = fs.original_y_pos = 0;
+    fs.original_h = 48; fs.original_w = 100;
+    std::vector<std::vector<unsigned char>> frames(25, std::vector<unsigned char>(48 * 100));
+    for (int i = 0; i < 25; ++i)
+        for (size_t j = 0; j < frames[i].size(); ++j) frames[i][j] = (unsigned char)((j * 7 + i * 13 + (j >> 5)) & 0xFF);
+    for (int i = 0; i < 25; ++i) { fs.resized_image_data = frames[i]; seeded.filter_image(fs); }   // prints PILA LLENA once
+    std::vector<unsigned char> want8(48 * 100);
+    for (int i = 0; i < 24; ++i)
+    {
+        const net::image_set r = seeded.get_filtered_image();
+        oracle_filter3x3(frames[i].data(), want8.data(), 48, 100, 0);
+        CHECK(r.original_h == 48 && r.original_w == 100 && r.resized_image_data == want8);
+    }
+    CHECK(seeded.get_filtered_image().resized_image_data.empty());     // PILA VACIA
 }
 
 int main(int argc, char **argv)

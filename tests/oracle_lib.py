@@ -57,6 +57,8 @@ def lib():
         L.oracle_quant_e4m3.argtypes = [fp, C.c_int64]
         L.oracle_quantize_rows.restype = None
         L.oracle_quantize_rows.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_void_p, fp, fp]
+        L.oracle_filter3x3.restype = None
+        L.oracle_filter3x3.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.oracle_linear.restype = None
         L.oracle_linear.argtypes = [fp, fp, fp, fp, C.c_int64, C.c_int, C.c_int]
         L.oracle_gelu.restype = None
@@ -144,6 +146,13 @@ def quantize_rows(w, post=1.0):
     sc = np.empty(rows, dtype=np.float32)
     lib().oracle_quantize_rows(_fp(w), rows, cols, post, w8.ctypes.data, _fp(wq), _fp(sc))
     return w8, wq, sc
+
+
+def filter3x3(frame, kind):
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    out = np.empty_like(frame)
+    lib().oracle_filter3x3(frame.ctypes.data, out.ctypes.data, frame.shape[0], frame.shape[1], kind)
+    return out
 
 
 def linear(a, w, bias=None):

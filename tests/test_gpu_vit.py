@@ -133,6 +133,37 @@ def test_deterministic_and_batch_independent():
     ctx.close()
 
 
+def test_full_size_batch_512_properties():
+    # BASELINE config 2 at its full size (ViT-B/16, bf16, 512 images = 100 864 token rows).  The oracle cannot run
+    # 512 ViT-B images in test time, so the full-size run is checked through size-independent properties:
+    #   * images are independent: any sub-batch run alone reproduces its rows of the big run bit for bit
+    #     (this is also what makes the 8-GPU image sharding exact),
+    #   * a permutation of the images permutes the logits,
+    #   * and eight of its rows are compared with the oracle directly.
+    cfg = S.CONFIGS["vit_base"]
+    B = 512
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_BF16, max_batch=B)
+    ctx.init_weights_seeded(0)
+    blob = ctx.export_weights()
+    din = vithip.DeviceBuffer(B * 224 * 224 * 3 * 4)
+    dout = vithip.DeviceBuffer(B * cfg["classes"] * 4)
+    ctx.fill_input_seeded(1, B, din.ptr)
+    ctx.forward_device(din.ptr, B, dout.ptr)
+    full = dout.to_numpy(np.float32, (B, cfg["classes"]))
+    assert np.isfinite(full).all()
+    images = din.to_numpy(np.float32, (B, 224, 224, 3))
+    assert np.array_equal(images, S.make_images(cfg, 1, B))          # device generator == numpy generator
+    for lo, hi in ((0, 8), (250, 263), (511, 512)):
+        assert np.array_equal(ctx.forward(images[lo:hi]), full[lo:hi]), (lo, hi)
+    perm = np.array([300, 7, 511, 0, 128, 64])
+    assert np.array_equal(ctx.forward(images[perm]), full[perm])
+    ref = O.vit_forward(cfg, blob, images[:8])
+    e = rel(full[:8], ref)
+    print(f"\n[full size] vit_base b512 bf16: rows 0-7 vs oracle {e:.3e}")
+    assert e <= TOL[vithip.DTYPE_BF16]
+    ctx.close()
+
+
 def test_concurrent_parts_give_bit_identical_logits():
     # vh_set_streams(n): the batch runs as n contiguous parts on n streams; images are independent, so every n
     # (and uneven splits: 5 images in 2, 3, 4 parts) must reproduce the single-stream logits bit for bit

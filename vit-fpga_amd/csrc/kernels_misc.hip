@@ -397,4 +397,61 @@ hipError_t launch_fold_ln(const float* w, const float* b, const float* gamma, co
 
 hipError_t init_kernel_attributes() { return hipSuccess; }
 
+// ---- 3x3 image filter on 8-bit single-channel frames (the reference's filter_image pipeline) --------------------
+// The reference's kernel `image_process` is absent (netFPGA.cpp:305 names it, no source, no bitstream), so its
+// arithmetic is a documented choice here: KIND 0 = 3x3 binomial blur (1 2 1 / 2 4 2 / 1 2 1, +8 >> 4), KIND 1 =
+// Sobel |gx| + |gy| saturated to 255; borders replicate the edge pixel.  Integer arithmetic: bit-exact against
+// the oracle.  HBM-bound (1 byte in + 1 byte out per pixel); a thread produces 4 adjacent pixels from 3 x 6 inputs.
+template <int KIND>
+__global__ void __launch_bounds__(256) filter3x3_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int h, int w) {
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    if (x0 >= w) return;
+    int p[3][6];
+    const bool fast = (w & 3) == 0 && x0 >= 4 && x0 + 8 <= w;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int yy = y + r - 1;
+        yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+        const uint8_t* row = in + (int64_t)yy * w;
+        if (fast) {
+            const uint32_t a = *(const uint32_t*)(row + x0 - 4), b = *(const uint32_t*)(row + x0), c = *(const uint32_t*)(row + x0 + 4);
+            p[r][0] = a >> 24;
+            p[r][1] = b & 0xFF; p[r][2] = (b >> 8) & 0xFF; p[r][3] = (b >> 16) & 0xFF; p[r][4] = b >> 24;
+            p[r][5] = c & 0xFF;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int xx = x0 + i - 1;
+                xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+                p[r][i] = row[xx];
+            }
+        }
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int v;
+        if (KIND == 0) {
+            v = (p[0][i] + 2 * p[0][i + 1] + p[0][i + 2] + 2 * (p[1][i] + 2 * p[1][i + 1] + p[1][i + 2]) + p[2][i] + 2 * p[2][i + 1] + p[2][i + 2] + 8) >> 4;
+        } else {
+            const int gx = (p[0][i + 2] + 2 * p[1][i + 2] + p[2][i + 2]) - (p[0][i] + 2 * p[1][i] + p[2][i]);
+            const int gy = (p[2][i] + 2 * p[2][i + 1] + p[2][i + 2]) - (p[0][i] + 2 * p[0][i + 1] + p[0][i + 2]);
+            v = (gx < 0 ? -gx : gx) + (gy < 0 ? -gy : gy);
+            v = v > 255 ? 255 : v;
+        }
+        packed |= (uint32_t)v << (8 * i);
+    }
+    uint8_t* o = out + (int64_t)y * w + x0;
+    if ((w & 3) == 0) *(uint32_t*)o = packed;
+    else
+        for (int i = 0; i < 4 && x0 + i < w; ++i) o[i] = (uint8_t)(packed >> (8 * i));
+}
+hipError_t launch_filter3x3(const uint8_t* in, uint8_t* out, int h, int w, int kind, hipStream_t s) {
+    if (h <= 0 || w <= 0 || (kind != 0 && kind != 1)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((w + 1023) / 1024), (unsigned)h), block(256);
+    if (kind == 0) hipLaunchKernelGGL(filter3x3_kernel<0>, grid, block, 0, s, in, out, h, w);
+    else hipLaunchKernelGGL(filter3x3_kernel<1>, grid, block, 0, s, in, out, h, w);
+    return hipGetLastError();
+}
+
 }  // namespace vh

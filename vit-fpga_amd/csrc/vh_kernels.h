@@ -63,6 +63,9 @@ hipError_t launch_fold_ln(const float* w, const float* b, const float* gamma, co
 hipError_t launch_dense_layer(const float* w, const float* b, const float* x, float* y, int n_in,
                               int n_out, int n_vec, int activation, hipStream_t stream);
 
+// 3x3 filter on 8-bit frames (filter_image): kind 0 = binomial blur, 1 = Sobel |gx|+|gy|
+hipError_t launch_filter3x3(const uint8_t* in, uint8_t* out, int h, int w, int kind, hipStream_t stream);
+
 hipError_t init_kernel_attributes();  // opt in to >64 KiB dynamic LDS, once per process
 
 }  // namespace vh

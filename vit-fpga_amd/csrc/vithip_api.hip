@@ -179,6 +179,19 @@ struct vh_ctx {
     std::string err;
 };
 
+// filter_image pipeline: a ring of in-flight 8-bit frames (reference: 24 slots, netFPGA.cpp:47-56, 292-365)
+struct vh_filter {
+    int device, height, width, kind;
+    struct Slot {
+        uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+        hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
+    };
+    std::vector<Slot> slot;
+    hipStream_t copy_in = nullptr, compute = nullptr, copy_out = nullptr;
+    int wr = 0, rd = 0, used = 0;
+    std::string err;
+};
+
 struct vh_mlp {
     int device, n_ins, n_layers, activation;
     std::vector<int> npl;
@@ -1225,6 +1238,104 @@ int vh_bench_gemm(int device, int64_t M, int N, int K, int epilogue, int dtype, 
 }
 
 // ---- MLP mode ------------------------------------------------------------------------------------
+// ---- filter_image pipeline --------------------------------------------------------------------------------------
+// submit: H2D of one frame -> 3x3 filter -> D2H, all asynchronous, chained by events (the reference's
+// clEnqueueWriteBuffer -> clEnqueueTask -> clEnqueueReadBuffer chain, netFPGA.cpp:323-329); collect: wait for the
+// OLDEST frame (clWaitForEvents on g_im_read_event[rd], :350).  Full / empty ring = VH_ERR_RING_FULL / _EMPTY.
+int vh_filter_destroy(vh_filter* f) {
+    if (!f) return VH_OK;
+    hipSetDevice(f->device);
+    if (f->copy_in) hipStreamSynchronize(f->copy_in);
+    if (f->compute) hipStreamSynchronize(f->compute);
+    if (f->copy_out) hipStreamSynchronize(f->copy_out);
+    for (auto& s : f->slot) {
+        if (s.h_in) hipHostFree(s.h_in);
+        if (s.h_out) hipHostFree(s.h_out);
+        if (s.d_in) hipFree(s.d_in);
+        if (s.d_out) hipFree(s.d_out);
+        if (s.in_done) hipEventDestroy(s.in_done);
+        if (s.k_done) hipEventDestroy(s.k_done);
+        if (s.out_done) hipEventDestroy(s.out_done);
+    }
+    if (f->copy_in) hipStreamDestroy(f->copy_in);
+    if (f->compute) hipStreamDestroy(f->compute);
+    if (f->copy_out) hipStreamDestroy(f->copy_out);
+    delete f;
+    return VH_OK;
+}
+
+int vh_filter_create(int device, int height, int width, int slots, int kind, vh_filter** out) {
+    if (!out) return fail(nullptr, VH_ERR_INVALID, "vh_filter_create: null argument");
+    *out = nullptr;
+    if (height <= 0 || width <= 0 || height > 16384 || width > 16384) return fail(nullptr, VH_ERR_INVALID, "vh_filter_create: frame size outside 1..16384");
+    if (slots < 1 || slots > 64) return fail(nullptr, VH_ERR_INVALID, "vh_filter_create: slots must be 1..64");
+    if (kind != VH_FILTER_BLUR3 && kind != VH_FILTER_SOBEL3) return fail(nullptr, VH_ERR_INVALID, "vh_filter_create: unknown filter kind %d", kind);
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    vh_filter* f = new vh_filter();
+    f->device = device; f->height = height; f->width = width; f->kind = kind;
+    const size_t n = (size_t)height * width;
+    hipError_t e = hipStreamCreateWithFlags(&f->copy_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->compute, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->copy_out, hipStreamNonBlocking);
+    f->slot.resize(slots);
+    for (auto& s : f->slot) {
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_in, n, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_out, n, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.d_in, n);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.d_out, n);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.in_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.k_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.out_done, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        vh_filter_destroy(f);
+        return fail(nullptr, VH_ERR_HIP, "vh_filter_create: %s", hipGetErrorString(e));
+    }
+    *out = f;
+    return VH_OK;
+}
+
+const char* vh_filter_last_error(const vh_filter* f) { return f ? f->err.c_str() : g_err.c_str(); }
+
+int vh_filter_free_slots(const vh_filter* f, int* n) {
+    if (!f || !n) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *n = (int)f->slot.size() - f->used;
+    return VH_OK;
+}
+
+int vh_filter_submit(vh_filter* f, const uint8_t* frame) {
+    if (!f || !frame) return fail(f ? &f->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (f->used == (int)f->slot.size()) return fail(&f->err, VH_ERR_RING_FULL, "ring full (PILA LLENA)");
+    HIPCHK(&f->err, hipSetDevice(f->device));
+    vh_filter::Slot& s = f->slot[f->wr];
+    const size_t n = (size_t)f->height * f->width;
+    memcpy(s.h_in, frame, n);
+    HIPCHK(&f->err, hipMemcpyAsync(s.d_in, s.h_in, n, hipMemcpyHostToDevice, f->copy_in));
+    HIPCHK(&f->err, hipEventRecord(s.in_done, f->copy_in));
+    HIPCHK(&f->err, hipStreamWaitEvent(f->compute, s.in_done, 0));
+    HIPCHK(&f->err, launch_filter3x3(s.d_in, s.d_out, f->height, f->width, f->kind, f->compute));
+    HIPCHK(&f->err, hipEventRecord(s.k_done, f->compute));
+    HIPCHK(&f->err, hipStreamWaitEvent(f->copy_out, s.k_done, 0));
+    HIPCHK(&f->err, hipMemcpyAsync(s.h_out, s.d_out, n, hipMemcpyDeviceToHost, f->copy_out));
+    HIPCHK(&f->err, hipEventRecord(s.out_done, f->copy_out));
+    f->wr = (f->wr + 1) % (int)f->slot.size();
+    ++f->used;
+    return VH_OK;
+}
+
+int vh_filter_collect(vh_filter* f, uint8_t* frame) {
+    if (!f || !frame) return fail(f ? &f->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (f->used == 0) return fail(&f->err, VH_ERR_RING_EMPTY, "ring empty (PILA VACIA)");
+    HIPCHK(&f->err, hipSetDevice(f->device));
+    vh_filter::Slot& s = f->slot[f->rd];
+    HIPCHK(&f->err, hipEventSynchronize(s.out_done));
+    memcpy(frame, s.h_out, (size_t)f->height * f->width);
+    f->rd = (f->rd + 1) % (int)f->slot.size();
+    --f->used;
+    return VH_OK;
+}
+
 int vh_mlp_create(int device, int n_ins, int n_layers, const int* n_p_l, int activation, vh_mlp** out) {
     if (!out || !n_p_l || n_ins <= 0 || n_layers <= 0) return fail(nullptr, VH_ERR_INVALID, "vh_mlp_create: bad argument");
     if (activation < VH_ACT_IDENTITY || activation > VH_ACT_GELU) return fail(nullptr, VH_ERR_INVALID, "unknown activation %d", activation);

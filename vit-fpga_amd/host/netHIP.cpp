@@ -21,6 +21,7 @@ namespace hip
     {
         const int IMAGE_HEIGHT = 1080; // netFPGA.h:14-15, only reported by get_filtered_image()
         const int IMAGE_WIDTH = 1920;
+        const int FILTER_SLOTS = 24; // BATCH_SIZE of the reference's ring (netFPGA.cpp:47)
 
         size_t floats_per_image(const vh_config &c)
         {
@@ -46,7 +47,7 @@ namespace hip
         : n_ins((int)data.n_ins), n_layers((int)data.n_p_l.size()), n_p_l(nullptr), n_neurons(0), n_params(0),
           params(nullptr), activations(VH_ACT_RELU2), bias(nullptr), n_sets(0), gradient_init(false),
           gradient_performance(0), forward_performance(0), device_init(false), device(0), vit_mode(false),
-          vcfg(), vit_seed(0), ring_slots(0), ring_batch(0), mlp(nullptr), vit(nullptr)
+          vcfg(), vit_seed(0), ring_slots(0), ring_batch(0), filter_kind(VH_FILTER_BLUR3), filt_h(0), filt_w(0), mlp(nullptr), vit(nullptr), filt(nullptr)
     {
         (void)derivate; // ignored by the reference as well
         if (n_layers <= 0 || n_ins <= 0)
@@ -93,7 +94,7 @@ namespace hip
         : n_ins((int)floats_per_image(cfg)), n_layers(cfg.layers), n_p_l(nullptr), n_neurons(0), n_params(0), params(nullptr),
           activations(VH_ACT_GELU), bias(nullptr), n_sets(0), gradient_init(false), gradient_performance(0),
           forward_performance(0), device_init(false), device(device_index), vit_mode(true), vcfg(cfg), vit_seed(seed),
-          ring_slots(0), ring_batch(0), mlp(nullptr), vit(nullptr)
+          ring_slots(0), ring_batch(0), filter_kind(VH_FILTER_BLUR3), filt_h(0), filt_w(0), mlp(nullptr), vit(nullptr), filt(nullptr)
     {
         if (vh_weight_blob_bytes(&vcfg) == 0)
             die("constructor", "unsupported vh_config");
@@ -113,8 +114,11 @@ namespace hip
             vh_mlp_destroy(mlp);
         if (vit)
             vh_destroy(vit);
+        if (filt)
+            vh_filter_destroy(filt);
         mlp = nullptr;
         vit = nullptr;
+        filt = nullptr;
         device_init = false;
         delete[] n_p_l;
         delete[] params;
@@ -133,8 +137,9 @@ namespace hip
         forward_performance = rh.forward_performance; device_init = rh.device_init; device = rh.device;
         vit_mode = rh.vit_mode; vcfg = rh.vcfg; vit_seed = rh.vit_seed; vit_blob = std::move(rh.vit_blob);
         ring_slots = rh.ring_slots; ring_batch = rh.ring_batch;
-        mlp = rh.mlp; vit = rh.vit;
-        rh.n_p_l = nullptr; rh.params = nullptr; rh.bias = nullptr; rh.mlp = nullptr; rh.vit = nullptr;
+        filter_kind = rh.filter_kind; filt_h = rh.filt_h; filt_w = rh.filt_w;
+        mlp = rh.mlp; vit = rh.vit; filt = rh.filt;
+        rh.n_p_l = nullptr; rh.params = nullptr; rh.bias = nullptr; rh.mlp = nullptr; rh.vit = nullptr; rh.filt = nullptr;
         rh.device_init = false;
     }
 
@@ -145,6 +150,7 @@ namespace hip
         gradient_performance = rh.gradient_performance; forward_performance = rh.forward_performance;
         device = rh.device; vit_mode = rh.vit_mode; vcfg = rh.vcfg; vit_seed = rh.vit_seed; vit_blob = rh.vit_blob;
         ring_slots = rh.ring_slots; ring_batch = rh.ring_batch;
+        filter_kind = rh.filter_kind; filt_h = filt_w = 0; // the copy builds its own pipeline on first use
         if (!vit_mode)
         {
             n_p_l = new int[n_layers];
@@ -158,7 +164,7 @@ namespace hip
     }
 
     net_hip::net_hip(net_hip &&rh)
-        : n_p_l(nullptr), params(nullptr), bias(nullptr), device_init(false), mlp(nullptr), vit(nullptr)
+        : n_p_l(nullptr), params(nullptr), bias(nullptr), device_init(false), mlp(nullptr), vit(nullptr), filt(nullptr)
     {
         steal(rh);
     }
@@ -418,14 +424,42 @@ namespace hip
 #endif
     }
 
-    // ---- image filter: out of scope (kernel `image_process` absent) ----
-    // Behaves like the reference with an empty ring: submissions are dropped with the reference's
-    // own overflow message, reads return an empty 1080x1920 image_set with its underflow message
-    // (netFPGA.cpp:330-333, 358-361).
+    // ---- image filter ----
+    // The reference pushes single-channel 8-bit frames through a kernel `image_process` whose source is absent, with a
+    // 24-slot ring of in-flight frames (netFPGA.cpp:292-365).  The ring behaviour is reproduced (non-blocking submit,
+    // FIFO collect, "PILA LLENA" / "PILA VACIA" and a dropped frame / an empty result on overflow / underflow); the
+    // arithmetic is this build's documented choice, a 3x3 filter (include/vithip.h, VH_FILTER_*).  The pipeline is
+    // created lazily for the size of the first frame, as the reference sizes its buffers from the first set (:305).
+    void net_hip::set_filter(int vh_filter_kind)
+    {
+        if (filt)
+            die("set_filter", "must be called before the first filter_image");
+        if (vh_filter_kind != VH_FILTER_BLUR3 && vh_filter_kind != VH_FILTER_SOBEL3)
+            die("set_filter", "unknown filter kind");
+        filter_kind = vh_filter_kind;
+    }
+
     void net_hip::filter_image(const net::image_set &set)
     {
-        (void)set;
-        cout << "PILA LLENA\n";
+        if (set.original_h == 0 || set.original_w == 0 || set.resized_image_data.size() < set.original_h * set.original_w)
+            die("filter_image", "resized_image_data holds fewer than original_h * original_w bytes");
+        if (filt && ((size_t)filt_h != set.original_h || (size_t)filt_w != set.original_w))
+            die("filter_image", "frame size differs from the first frame's");
+        if (!filt)
+        {
+            if (vh_filter_create(device, (int)set.original_h, (int)set.original_w, FILTER_SLOTS, filter_kind, &filt) != VH_OK)
+                die("vh_filter_create", vh_last_error(nullptr));
+            filt_h = (int)set.original_h;
+            filt_w = (int)set.original_w;
+        }
+        const int rc = vh_filter_submit(filt, set.resized_image_data.data());
+        if (rc == VH_ERR_RING_FULL)
+        {
+            cout << "PILA LLENA\n"; // netFPGA.cpp:330-333: the frame is dropped
+            return;
+        }
+        if (rc != VH_OK)
+            die("vh_filter_submit", vh_filter_last_error(filt));
     }
 
     net::image_set net_hip::get_filtered_image()
@@ -433,9 +467,23 @@ namespace hip
         net::image_set out;
         out.original_x_pos = 0;
         out.original_y_pos = 0;
-        out.original_h = IMAGE_HEIGHT;
-        out.original_w = IMAGE_WIDTH;
-        cout << "PILA VACIA\n";
+        out.original_h = filt ? (size_t)filt_h : (size_t)IMAGE_HEIGHT; // the reference always reports 1080 x 1920 (:340-343)
+        out.original_w = filt ? (size_t)filt_w : (size_t)IMAGE_WIDTH;
+        if (!filt)
+        {
+            cout << "PILA VACIA\n";
+            return out;
+        }
+        out.resized_image_data.resize((size_t)filt_h * filt_w);
+        const int rc = vh_filter_collect(filt, out.resized_image_data.data());
+        if (rc == VH_ERR_RING_EMPTY)
+        {
+            cout << "PILA VACIA\n"; // netFPGA.cpp:358-361
+            out.resized_image_data.clear();
+            return out;
+        }
+        if (rc != VH_OK)
+            die("vh_filter_collect", vh_filter_last_error(filt));
         return out;
     }
 }

@@ -58,9 +58,11 @@ namespace hip
         vh_config vcfg;
         uint64_t vit_seed;
         int ring_slots, ring_batch; // 0 = no pipeline
+        int filter_kind, filt_h, filt_w;
         std::string vit_blob;  // host copy of the canonical blob when constructed from one
         vh_mlp *mlp;
         vh_ctx *vit;
+        vh_filter *filt;
         void release();
         void copy_from(const net_hip &rh);
         void steal(net_hip &rh);
@@ -98,6 +100,7 @@ namespace hip
         // model shape from the file's header (host only; the device is still touched lazily by the first forward).
         static net_hip from_file(const char *blob_path, int vh_dtype, int device_index = 0);
         void save_weights(const char *blob_path);
+        void set_filter(int vh_filter_kind);        // VH_FILTER_*; before the first filter_image
         void set_pipeline(int slots, int max_batch_per_slot);
         bool submit_forward(const std::vector<DATA_TYPE> &inputs);
         std::vector<DATA_TYPE> collect_forward();

@@ -65,6 +65,12 @@ SYMBOLS = {
     "vh_last_kernel_ms": (_i, [_vp, C.POINTER(C.c_double)]),
     "vh_profile_forward": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_double), _i, _pi]),
     "vh_stage_name": (C.c_char_p, [_i]),
+    "vh_filter_create": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_void_p)]),
+    "vh_filter_destroy": (_i, [_vp]),
+    "vh_filter_free_slots": (_i, [_vp, _pi]),
+    "vh_filter_submit": (_i, [_vp, _vp]),
+    "vh_filter_collect": (_i, [_vp, _vp]),
+    "vh_filter_last_error": (C.c_char_p, [_vp]),
     "vh_blob_file_config": (_i, [C.c_char_p, C.POINTER(Config)]),
     "vh_save_weights_file": (_i, [_vp, C.c_char_p]),
     "vh_load_weights_file": (_i, [_vp, C.c_char_p]),
@@ -193,6 +199,49 @@ class DeviceBuffer:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+FILTER_BLUR3, FILTER_SOBEL3 = 0, 1
+
+
+class FilterPipeline:
+    """vh_filter wrapper: the filter_image / get_filtered_image ring."""
+
+    def __init__(self, height, width, slots=24, kind=FILTER_BLUR3, device=0):
+        self.shape = (height, width)
+        h = C.c_void_p()
+        _check(lib().vh_filter_create(device, height, width, slots, kind, C.byref(h)))
+        self.h = h.value
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise VhError(rc, lib().vh_filter_last_error(self.h).decode())
+
+    def free_slots(self):
+        n = C.c_int(0)
+        self._chk(lib().vh_filter_free_slots(self.h, C.byref(n)))
+        return n.value
+
+    def submit(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert frame.shape == self.shape
+        self._chk(lib().vh_filter_submit(self.h, frame.ctypes.data))
+
+    def collect(self):
+        out = np.empty(self.shape, dtype=np.uint8)
+        self._chk(lib().vh_filter_collect(self.h, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().vh_filter_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 
