@@ -26,7 +26,7 @@ def main():
     cnt = defaultdict(lambda: defaultdict(int))
     dur = defaultdict(list)
     for d in sys.argv[1:]:
-        for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+        for f in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
             seen = set()
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
