@@ -212,7 +212,7 @@ int vh_op_gemm(const void* a16_dev, const void* w16_dev, const float* bias_dev, 
  * out = epilogue(w_scale[n] * sum_k a8[m,k] w8[n,k] + bias[n]);  VH_EPI_BIAS -> bf16, VH_EPI_BIAS_GELU -> e4m3
  * (saturating), VH_EPI_BIAS_RESID (out += ...) / VH_EPI_BIAS_F32 -> fp32.  K % 128 == 0, N % 4 == 0. */
 int vh_op_gemm_fp8(const void* a8, const void* w8, const float* w_scale, const float* bias, void* out, int64_t M,
-                   int N, int K, int epilogue, void* stream);
+                   int N, int K, int epilogue, int variant /* 0 auto, 5, 7 */, void* stream);
 /* the load-time weight quantiser: s0 = amax(row)/448 (1 for an all-zero row), w8 = rne_e4m3(w / s0),
  * scale[row] = s0 * post_scale */
 int vh_op_quantize_rows(const float* w, int rows, int cols, float post_scale, void* w8, float* scale, void* stream);

@@ -72,19 +72,20 @@ def _operands(M, N, K, seed):
     return a, O.e4m3_bytes(a), w8, wq, sc, bias
 
 
+@pytest.mark.parametrize("variant", [5, 7])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 260, 384), (1000, 768, 768), (64, 3072, 256), (5, 8, 128)])
-def test_gemm_fp32_out_matches_fp32_accumulation(M, N, K):
+def test_gemm_fp32_out_matches_fp32_accumulation(M, N, K, variant):
     a, a8, w8, wq, sc, bias = _operands(M, N, K, 21)
     ref = O.linear(a, wq) * sc[None, :] + bias[None, :]
     out = vithip.DeviceBuffer(M * N * 4)
-    vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, out.ptr, M, N, K, vithip.EPI_BIAS_F32)
+    vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, out.ptr, M, N, K, vithip.EPI_BIAS_F32, variant)
     got = out.to_numpy(np.float32, (M, N))
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= 2e-5 * scale, np.abs(got - ref).max() / scale
     # residual form: out += ...
     x0 = S.fill(M * N, 22, 4, 0).reshape(M, N)
     xb = dev(x0)
-    vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, xb.ptr, M, N, K, vithip.EPI_BIAS_RESID)
+    vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, xb.ptr, M, N, K, vithip.EPI_BIAS_RESID, variant)
     got = xb.to_numpy(np.float32, (M, N))
     assert np.abs(got - (x0 + ref)).max() <= 2e-5 * max(scale, 1.0)
 

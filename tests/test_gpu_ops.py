@@ -114,7 +114,7 @@ GEMM_SHAPES = [  # M, N, K — ragged M, N not a tile multiple, every K class of
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_bias_f32(dt, variant, M, N, K):
@@ -130,7 +130,7 @@ def test_gemm_bias_f32(dt, variant, M, N, K):
     assert np.abs(got - ref).max() <= 2e-5 * scale, np.abs(got - ref).max() / scale
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_integer_exact_asymmetric(dt, variant):
     # exact small-integer data with an asymmetric W catches any row/col or k-order mix-up bitwise
@@ -146,7 +146,7 @@ def test_gemm_integer_exact_asymmetric(dt, variant):
     assert np.array_equal(out.to_numpy(np.float32, (M, N)), ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("epi", ["bias", "gelu", "resid"])
 def test_gemm_epilogues(dt, variant, epi):
@@ -172,7 +172,7 @@ def test_gemm_epilogues(dt, variant, epi):
         assert_close16(got, ref, dt, extra=3e-5 * np.abs(lin).max())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_patch_epilogue(dt, variant):
     # rows of the patch matrix are remapped to token rows 1..NP of each image, + pos-emb
@@ -282,7 +282,7 @@ def test_rowstats_cast_and_finalize(dt):
     assert np.abs(st2.to_numpy(np.float32, (rows, 2)) - want).max() <= 1e-5 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("gelu", [False, True])
 def test_gemm_lnfold_equals_layernorm_then_linear(dt, variant, gelu):
@@ -313,7 +313,7 @@ def test_gemm_lnfold_equals_layernorm_then_linear(dt, variant, gelu):
     assert np.abs(got - true).max() / np.abs(true).max() <= (3e-2 if dt == vithip.DTYPE_BF16 else 4e-3)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_resid_ln_epilogue(dt, variant):
     M, N, K = 400, 512, 192

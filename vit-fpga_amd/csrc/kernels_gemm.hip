@@ -24,6 +24,8 @@
 //   * 1-D grid remapped so that the workgroups that share an XCD (blockIdx % 8) walk a
 //     contiguous run of tiles, n fastest: neighbours reuse the same A panel from that XCD's L2.
 //   * ragged M / N: loads clamp the row index, stores are predicated (N % 4 == 0, K % 64 == 0).
+#include <cstdlib>
+
 #include "gemm_epilogue.h"
 #include "vh_kernels.h"
 
@@ -152,11 +154,11 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
 }
 
 template <typename T, int EPI>
-hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t s);  // kernels_gemm5.hip
+hipError_t launch_gemm_pingpong(const GemmArgs& g, int mode, hipStream_t s);  // kernels_gemm5.hip; mode = variant - 5
 
 template <typename T, int EPI>
 static hipError_t launch_tile(const GemmArgs& g, int variant, hipStream_t s) {
-    if (variant == 5 || variant == 6) return launch_gemm_pingpong<T, EPI>(g, variant == 6, s);
+    if (variant >= 5 && variant <= 7) return launch_gemm_pingpong<T, EPI>(g, variant - 5, s);
     if (variant == 2) return launch_one<T, 256, 256, 2, 4, EPI>(g, s);
     return launch_one<T, 128, 128, 2, 2, EPI>(g, s);
 }
@@ -176,9 +178,19 @@ static hipError_t launch_epi(const GemmArgs& g, int variant, hipStream_t s) {
     }
 }
 
+// which ping-pong form large shapes take: 5 (two A stages), 6 (persistent) or 7 (three A stages); VH_GEMM_PP overrides
+int gemm_pp_variant() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("VH_GEMM_PP");
+        v = e ? atoi(e) : 5;
+        if (v < 5 || v > 7) v = 5;
+    }
+    return v;
+}
 int gemm_pick_variant(int64_t M, int N) {
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-    return t256 >= 256 ? 5 : 1;  // the 256x256 ping-pong kernel only when it still fills all 256 CUs
+    return t256 >= 256 ? gemm_pp_variant() : 1;  // the 256x256 ping-pong kernel only when it still fills all 256 CUs
 }
 
 const char* gemm_check(const GemmArgs& g) {
@@ -191,7 +203,7 @@ const char* gemm_check(const GemmArgs& g) {
     if (g.epilogue == VH_EPI_RESID_LN && (!g.out16 || !g.partials || g.N % 256)) return "gemm: RESID_LN needs out16, partials and N % 256 == 0";
     if (g.epilogue == VH_EPI_PATCH && (!g.aux || g.aux_i <= 0)) return "gemm: EPI_PATCH needs pos-emb and patches/image";
     if (g.dtype != VH_DTYPE_BF16 && g.dtype != VH_DTYPE_FP16) return "gemm: dtype";
-    if (g.variant < 0 || g.variant > 6) return "gemm: variant";
+    if (g.variant < 0 || g.variant > 7) return "gemm: variant";
     if (g.variant == 3 || g.variant == 4) return "gemm: variants 3/4 (BK=32 pipeline) were removed";
     if (!g.a || !g.w || !g.bias || !g.out) return "gemm: null pointer";
     return nullptr;

@@ -63,7 +63,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {  // bijective on [0, 
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
 }
 
-template <typename T, int EPI, bool PERSIST, bool F8 = false>
+template <typename T, int EPI, bool PERSIST, bool F8 = false, int AST = 2>
 __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
@@ -73,6 +73,10 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     constexpr int BM = 256, BN = 256;
     constexpr int KT_BYTES = 128;                  // one K-tile row: 64 16-bit or 128 8-bit elements
     constexpr int STAGE_BYTES = 65536, W_OFF = 32768;
+    // AST = number of LDS stages of the A (activation) operand.  2: stage s = [A 32 KiB | W 32 KiB] at s * 64 KiB.
+    // 3 (variant 7): W stages at 0 / 32 KiB, A stages at 64 + 32 s KiB (160 KiB, the whole LDS): A of tile k+2 is
+    // issued in L0(k), a full K-tile earlier than with two stages, and the counted wait that closed C1 disappears.
+    static_assert(AST == 2 || (AST == 3 && !PERSIST), "three A stages: one tile per workgroup only");
     const char* const A = (const char*)Av;
     const char* const W = (const char*)Wv;
     const int64_t row_bytes = (int64_t)K * (F8 ? 1 : 2);
@@ -106,15 +110,17 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         }
     };
     const int dma_off = grp * 16384 + wn * 1024;  // + i * 4096
-    auto issue_a = [&](int kt) {
-        char* dst = smem + (kt & 1) * STAGE_BYTES + dma_off;
+    auto a_off = [&](int kt, int kt3) { return AST == 2 ? (kt & 1) * STAGE_BYTES : 2 * W_OFF + kt3 * 32768; };
+    auto w_off = [&](int kt) { return AST == 2 ? (kt & 1) * STAGE_BYTES + W_OFF : (kt & 1) * W_OFF; };
+    auto issue_a = [&](int kt, int kt3 = 0) {
+        char* dst = smem + a_off(kt, kt3) + dma_off;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gA[i] + kt * KT_BYTES),
                                              (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
     };
     auto issue_w = [&](int kt) {
-        char* dst = smem + (kt & 1) * STAGE_BYTES + W_OFF + dma_off;
+        char* dst = smem + w_off(kt) + dma_off;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gW[i] + kt * KT_BYTES),
@@ -126,8 +132,8 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     // 16-bit: k-step 0 / 1 = chunk fq / 4+fq; fp8: the lane's 32 k-bytes = chunks 2fq and 2fq+1
     const int off0 = frow * 128 + (((F8 ? 2 * fq : fq) ^ (frow & 7)) << 4);
     const int off1 = frow * 128 + (((F8 ? 2 * fq + 1 : 4 | fq) ^ (frow & 7)) << 4);
-    const int xbase = grp * 16384;          // rows 128*grp ..
-    const int wbase = W_OFF + wn * 8192;    // rows 64*wn ..
+    const int xbase = grp * 16384;          // rows 128*grp ..  (inside an A stage)
+    const int wbase = wn * 8192;            // rows 64*wn ..    (inside a W stage)
 
     const int nk = (int)(row_bytes / KT_BYTES);
 
@@ -137,7 +143,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     issue_a(0);
     if (nk > 1) {
         issue_w(1);
-        issue_a(1);
+        issue_a(1, 1);
     }
 
     while (true) {
@@ -159,14 +165,16 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                 const u32x4 lo = *(const u32x4*)(p + off0), hi = *(const u32x4*)(p + off1);
                 return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
             };
-            for (int kt = 0; kt < nk; ++kt) {
-                const char* st = smem + (kt & 1) * STAGE_BYTES;
+            for (int kt = 0, k3 = 0; kt < nk; ++kt, k3 = k3 == 2 ? 0 : k3 + 1) {
+                const char* sa = smem + a_off(kt, k3) + xbase;
+                const char* sw = smem + w_off(kt) + wbase;
                 // ---- L0 ----
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) wf[ni] = ld8(st + wbase + ni * 2048);
+                for (int ni = 0; ni < NI; ++ni) wf[ni] = ld8(sw + ni * 2048);
 #pragma unroll
-                for (int mi = 0; mi < MI / 2; ++mi) xf[mi] = ld8(st + xbase + mi * 2048);
-                if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
+                for (int mi = 0; mi < MI / 2; ++mi) xf[mi] = ld8(sa + mi * 2048);
+                if (AST == 3) { if (kt + 2 < nk) issue_a(kt + 2, k3 == 0 ? 2 : k3 - 1); }
+                else if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 pp_barrier();
                 // ---- C0 ----
@@ -180,11 +188,11 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                 pp_barrier();
                 // ---- L1 ----
 #pragma unroll
-                for (int mi = 0; mi < MI / 2; ++mi) xf[mi] = ld8(st + xbase + (MI / 2 + mi) * 2048);
+                for (int mi = 0; mi < MI / 2; ++mi) xf[mi] = ld8(sa + (MI / 2 + mi) * 2048);
                 if (kt + 2 < nk) {
                     issue_w(kt + 2);
-                    pp_wait_vmcnt<8>();
-                } else if (kt + 1 < nk) {
+                    pp_wait_vmcnt<8>();   // AST 3: all but A(k+2), W(k+2) => A(k+1) and W(k+1) landed
+                } else if (AST == 2 && kt + 1 < nk) {
                     pp_wait_vmcnt<4>();
                 } else {
                     pp_wait_vmcnt<0>();
@@ -199,23 +207,27 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                     for (int ni = 0; ni < NI; ++ni)
                         acc[MI / 2 + mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf[mi], acc[MI / 2 + mi][ni], 0, 0, 0, unit, 0, unit);
                 __builtin_amdgcn_s_setprio(0);
-                if (kt + 2 < nk) pp_wait_vmcnt<4>();
-                else pp_wait_vmcnt<0>();
+                if (AST == 2) {
+                    if (kt + 2 < nk) pp_wait_vmcnt<4>();
+                    else pp_wait_vmcnt<0>();
+                }
                 pp_barrier();
             }
         } else {
         vec8 wf0[NI], wf1[NI], xf[MI];
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* st = smem + (kt & 1) * STAGE_BYTES;
+        for (int kt = 0, k3 = 0; kt < nk; ++kt, k3 = k3 == 2 ? 0 : k3 + 1) {
+            const char* sa = smem + a_off(kt, k3) + xbase;
+            const char* sw = smem + w_off(kt) + wbase;
             // ---- L0 ------------------------------------------------------------------------------------------------
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                wf0[ni] = *(const vec8*)(st + wbase + ni * 2048 + off0);
-                wf1[ni] = *(const vec8*)(st + wbase + ni * 2048 + off1);
+                wf0[ni] = *(const vec8*)(sw + ni * 2048 + off0);
+                wf1[ni] = *(const vec8*)(sw + ni * 2048 + off1);
             }
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off0);
-            if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
+            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(sa + mi * 2048 + off0);
+            if (AST == 3) { if (kt + 2 < nk) issue_a(kt + 2, k3 == 0 ? 2 : k3 - 1); }
+            else if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             pp_barrier();
             // ---- C0 ------------------------------------------------------------------------------------------------
@@ -228,11 +240,11 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             pp_barrier();
             // ---- L1 ------------------------------------------------------------------------------------------------
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(st + xbase + mi * 2048 + off1);
+            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(sa + mi * 2048 + off1);
             if (kt + 2 < nk) {
                 issue_w(kt + 2);
-                pp_wait_vmcnt<8>();
-            } else if (kt + 1 < nk) {
+                pp_wait_vmcnt<8>();   // AST 3: all but A(k+2), W(k+2) => A(k+1) and W(k+1) landed
+            } else if (AST == 2 && kt + 1 < nk) {
                 pp_wait_vmcnt<4>();
             } else {
                 pp_wait_vmcnt<0>();
@@ -246,8 +258,10 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf1[ni], xf[mi], acc[mi][ni]);
             __builtin_amdgcn_s_setprio(0);
-            if (kt + 2 < nk) pp_wait_vmcnt<4>();
-            else pp_wait_vmcnt<0>();
+            if (AST == 2) {
+                if (kt + 2 < nk) pp_wait_vmcnt<4>();
+                else pp_wait_vmcnt<0>();
+            }
             pp_barrier();
         }
         }
@@ -282,73 +296,72 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         if (nk > 1) {
             pp_barrier();  // every wave is done with its staging slice of stage 1
             issue_w(1);
-            issue_a(1);
+            issue_a(1, 1);
         }
         t = t_next;
     }
 }
 
-template <typename T, int EPI, bool F8>
-static hipError_t launch_pp(const GemmArgs& g, bool persistent, hipStream_t s) {
-    const int tiles_m = (int)((g.M + 255) / 256), tiles_n = (g.N + 255) / 256;
-    constexpr size_t lds = 131072;
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        num_cu = prop.multiProcessorCount;
+// mode 0: one tile per workgroup (variant 5); 1: persistent (6); 2: one tile per workgroup, three A stages (7)
+template <typename T, int EPI, bool F8, bool PERSIST, int AST>
+static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int tiles_n, hipStream_t s) {
+    constexpr size_t lds = AST == 3 ? 163840 : 131072;
+    auto k = gemm_nt_pp_kernel<T, EPI, PERSIST, F8, AST>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
     }
-    const int ntiles = tiles_m * tiles_n;
-    if (persistent) {
-        auto k = gemm_nt_pp_kernel<T, EPI, true, F8>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(k, dim3(ntiles < num_cu ? ntiles : num_cu), dim3(512), lds, s, g.a,
-                           g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n,
-                           g.stats, g.out16, g.partials);
-    } else {
-        auto k = gemm_nt_pp_kernel<T, EPI, false, F8>;
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(k, dim3(ntiles), dim3(512), lds, s, g.a, g.w,
-                           g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n, g.stats, g.out16, g.partials);
-    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
+                       tiles_n, g.stats, g.out16, g.partials);
     return hipGetLastError();
 }
 
+template <typename T, int EPI, bool F8>
+static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
+    const int tiles_m = (int)((g.M + 255) / 256), tiles_n = (g.N + 255) / 256;
+    const int ntiles = tiles_m * tiles_n;
+    if (mode == 2) return launch_pp_one<T, EPI, F8, false, 3>(g, ntiles, tiles_m, tiles_n, s);
+    if constexpr (!F8) {
+        if (mode == 1) {
+            static int num_cu = 0;
+            if (!num_cu) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+                num_cu = prop.multiProcessorCount;
+            }
+            return launch_pp_one<T, EPI, F8, true, 2>(g, ntiles < num_cu ? ntiles : num_cu, tiles_m, tiles_n, s);
+        }
+    }
+    return launch_pp_one<T, EPI, F8, false, 2>(g, ntiles, tiles_m, tiles_n, s);
+}
+
 template <typename T, int EPI>
-hipError_t launch_gemm_pingpong(const GemmArgs& g, bool persistent, hipStream_t s) {
-    return launch_pp<T, EPI, false>(g, persistent, s);
+hipError_t launch_gemm_pingpong(const GemmArgs& g, int mode, hipStream_t s) {
+    return launch_pp<T, EPI, false>(g, mode, s);
 }
 
 #define VH_INST(T)                                                                                     \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS>(const GemmArgs&, bool, hipStream_t);       \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_GELU>(const GemmArgs&, bool, hipStream_t);  \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_RESID>(const GemmArgs&, bool, hipStream_t); \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_F32>(const GemmArgs&, bool, hipStream_t);   \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_PATCH>(const GemmArgs&, bool, hipStream_t);       \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD>(const GemmArgs&, bool, hipStream_t);      \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD_GELU>(const GemmArgs&, bool, hipStream_t); \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_LN>(const GemmArgs&, bool, hipStream_t);
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS>(const GemmArgs&, int, hipStream_t);       \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_GELU>(const GemmArgs&, int, hipStream_t);  \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_RESID>(const GemmArgs&, int, hipStream_t); \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_BIAS_F32>(const GemmArgs&, int, hipStream_t);   \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_PATCH>(const GemmArgs&, int, hipStream_t);       \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD>(const GemmArgs&, int, hipStream_t);      \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD_GELU>(const GemmArgs&, int, hipStream_t); \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_LN>(const GemmArgs&, int, hipStream_t);
 VH_INST(BF16)
 VH_INST(FP16)
 
 // fp8 operands: 16-bit results are bf16; fc1 writes e4m3 (gemm_epilogue8)
 hipError_t launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
     switch (g.epilogue) {
-        case VH_EPI_BIAS: return launch_pp<BF16, VH_EPI_BIAS, true>(g, false, s);
-        case VH_EPI_BIAS_GELU: return launch_pp<BF16, VH_EPI_BIAS_GELU, true>(g, false, s);
-        case VH_EPI_BIAS_RESID: return launch_pp<BF16, VH_EPI_BIAS_RESID, true>(g, false, s);
-        case VH_EPI_BIAS_F32: return launch_pp<BF16, VH_EPI_BIAS_F32, true>(g, false, s);
+        case VH_EPI_BIAS: return launch_pp<BF16, VH_EPI_BIAS, true>(g, (g.variant ? g.variant : gemm_pp_variant()) == 7 ? 2 : 0, s);
+        case VH_EPI_BIAS_GELU: return launch_pp<BF16, VH_EPI_BIAS_GELU, true>(g, (g.variant ? g.variant : gemm_pp_variant()) == 7 ? 2 : 0, s);
+        case VH_EPI_BIAS_RESID: return launch_pp<BF16, VH_EPI_BIAS_RESID, true>(g, (g.variant ? g.variant : gemm_pp_variant()) == 7 ? 2 : 0, s);
+        case VH_EPI_BIAS_F32: return launch_pp<BF16, VH_EPI_BIAS_F32, true>(g, (g.variant ? g.variant : gemm_pp_variant()) == 7 ? 2 : 0, s);
         default: return hipErrorInvalidValue;
     }
 }

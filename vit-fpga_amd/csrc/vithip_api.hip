@@ -1105,13 +1105,14 @@ int vh_op_gemm(const void* a, const void* w, const float* bias, void* out, int64
     return VH_OK;
 }
 int vh_op_gemm_fp8(const void* a8, const void* w8, const float* w_scale, const float* bias, void* out, int64_t M, int N, int K,
-                   int epi, void* stream) {
+                   int epi, int variant, void* stream) {
+    if (variant != 0 && variant != 5 && variant != 7) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: variant must be 0, 5 or 7");
     if (!a8 || !w8 || !w_scale || !bias || !out) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: null pointer");
     if (M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 4) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: need K %% 128 == 0 and N %% 4 == 0");
     if (M > 0x7FFFFFFF / 2) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: M too large");
     if (epi != VH_EPI_BIAS && epi != VH_EPI_BIAS_GELU && epi != VH_EPI_BIAS_RESID && epi != VH_EPI_BIAS_F32)
         return fail(nullptr, VH_ERR_UNSUPPORTED, "gemm_fp8: epilogue %d not available", epi);
-    GemmArgs g{a8, w8, bias, out, M, N, K, epi, w_scale, 0, VH_DTYPE_FP8, 0};
+    GemmArgs g{a8, w8, bias, out, M, N, K, epi, w_scale, 0, VH_DTYPE_FP8, variant};
     OPCHK(launch_gemm_fp8(g, (hipStream_t)stream));
     OPCHK(hipStreamSynchronize((hipStream_t)stream));
     return VH_OK;

@@ -87,7 +87,7 @@ SYMBOLS = {
     "vh_debug_read": (_i, [_vp, _i, _vp, _sz]),
     "vh_debug_set_layers": (_i, [_vp, _i]),
     "vh_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp]),
-    "vh_op_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "vh_op_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "vh_op_quantize_rows": (_i, [_vp, _i, _i, C.c_float, _vp, _vp, _vp]),
     "vh_op_gemm_ex": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "vh_op_rowstats_cast": (_i, [_vp, _i64, _i, _f, _vp, _vp, _i, _vp]),
@@ -430,8 +430,8 @@ def op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, dtype, aux_ptr=N
     _check(lib().vh_op_gemm(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, aux_ptr, aux_i, dtype, variant, None))
 
 
-def op_gemm_fp8(a8_ptr, w8_ptr, scale_ptr, bias_ptr, out_ptr, M, N, K, epilogue):
-    _check(lib().vh_op_gemm_fp8(a8_ptr, w8_ptr, scale_ptr, bias_ptr, out_ptr, M, N, K, epilogue, None))
+def op_gemm_fp8(a8_ptr, w8_ptr, scale_ptr, bias_ptr, out_ptr, M, N, K, epilogue, variant=0):
+    _check(lib().vh_op_gemm_fp8(a8_ptr, w8_ptr, scale_ptr, bias_ptr, out_ptr, M, N, K, epilogue, variant, None))
 
 
 def op_quantize_rows(w_ptr, rows, cols, post_scale, w8_ptr, scale_ptr):
