@@ -58,7 +58,7 @@ __device__ __forceinline__ float cross_half_sum(float v) {
 }
 
 template <typename T, bool PERSIST, typename TO = T>   // TO: output element (T, or E4M3 on the fp8 path)
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, PERSIST ? 2 : 4)   // one-shot form: <= 128 VGPRs, two 7-wave workgroups per CU put 4 waves on a SIMD
 attention_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __restrict__ out,
                  int tokens, int heads, int slabs, int ntiles, int nitems) {
     using elem = typename T::elem;
@@ -152,14 +152,32 @@ attention_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __
             const char* vb0 = Vs + vrow0 * 128 + (vcolb ^ vx);
             const char* vb1 = Vs + vrow0 * 128 + ((vcolb + 64) ^ vx);
 
-            auto tile = [&](int kt, auto masked) {
-                // ---- S^T tile: 32 keys x 32 queries ---------------------------------------------------
+            // S^T tile: 32 keys x 32 queries
+            auto qk = [&](int kt) {
                 f32x16 s;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = 0.f;
                 const char* kp = kbase + kt * 4096;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) s = T::mfma32(*(const vec8*)(kp + kofs[ks]), qf[ks], s);
+                return s;
+            };
+            // V^T fragments of one 32-key tile: [k-step][column block] (hardware-transposing reads)
+            struct VFrag { vec8 f[2][2]; };
+            auto load_v = [&](int kt) {
+                VFrag v;
+                const char* v0 = vb0 + kt * 4096;
+                const char* v1 = vb1 + kt * 4096;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const vec4 a0 = T::tr_read(v0 + ks * 2048), c0 = T::tr_read(v0 + ks * 2048 + 1024);
+                    const vec4 a1 = T::tr_read(v1 + ks * 2048), c1 = T::tr_read(v1 + ks * 2048 + 1024);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v.f[ks][0][j] = a0[j]; v.f[ks][0][4 + j] = c0[j]; v.f[ks][1][j] = a1[j]; v.f[ks][1][4 + j] = c1[j]; }
+                }
+                return v;
+            };
+            auto softmax_pv = [&](int kt, f32x16 s, const VFrag& vfr, auto masked) {
                 if constexpr (decltype(masked)::value) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -189,31 +207,28 @@ attention_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __
                 }
                 lsum += psum;
                 // ---- O^T += V^T P^T ----------------------------------------------------------------------
-                const char* v0 = vb0 + kt * 4096;
-                const char* v1 = vb1 + kt * 4096;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     vec8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (elem)s[8 * ks + j];
-                    {
-                        const vec4 a = T::tr_read(v0 + ks * 2048), c = T::tr_read(v0 + ks * 2048 + 1024);
-                        vec8 vf;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { vf[j] = a[j]; vf[4 + j] = c[j]; }
-                        o0 = T::mfma32(vf, pf, o0);
-                    }
-                    {
-                        const vec4 a = T::tr_read(v1 + ks * 2048), c = T::tr_read(v1 + ks * 2048 + 1024);
-                        vec8 vf;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { vf[j] = a[j]; vf[4 + j] = c[j]; }
-                        o1 = T::mfma32(vf, pf, o1);
-                    }
+                    o0 = T::mfma32(vfr.f[ks][0], pf, o0);
+                    o1 = T::mfma32(vfr.f[ks][1], pf, o1);
                 }
             };
-            for (int kt = 0; kt + 1 < ntiles; ++kt) tile(kt, std::false_type{});
-            tile(ntiles - 1, std::true_type{});   // only the last tile can hold keys >= tokens
+            // software pipeline: the V fragments of tile k and the score MFMAs of tile k+1 are issued ahead of the
+            // softmax of tile k, so LDS latency and the matrix pipe sit under the wave's own exp/max/convert stream
+            f32x16 s_cur = qk(0);
+            for (int kt = 0; kt + 1 < ntiles; ++kt) {
+                const VFrag vfr = load_v(kt);
+                const f32x16 s_nxt = qk(kt + 1);
+                softmax_pv(kt, s_cur, vfr, std::false_type{});
+                s_cur = s_nxt;
+            }
+            {
+                const VFrag vfr = load_v(ntiles - 1);
+                softmax_pv(ntiles - 1, s_cur, vfr, std::true_type{});   // only the last tile can hold keys >= tokens
+            }
 
             // ---- normalise and store: lane holds O[q][32*db + 8*rg + 4*hl + 0..3] ------------------
             const float ltot = cross_half_sum(lsum);
