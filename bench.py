@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time table to stderr")
     ap.add_argument("--host-path", action="store_true",
                     help="also measure the PCIe-inclusive rate through the pinned submit/collect ring (extra object, never `value`)")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as a hipGraph (small batches are launch-bound)")
     ap.add_argument("--streams", type=int, default=0, help="split every forward into N concurrent parts (0 = library default, 1)")
     args = ap.parse_args()
 
@@ -71,6 +72,8 @@ def main():
     if args.streams > 0:
         ctx.set_streams(args.streams)
     streams = ctx.get_streams()
+    if args.graph:
+        ctx.set_graph(True)
 
     # ---- weights: rank 0 generates, RCCL broadcast of the canonical fp32 blob ---------------------
     if use_dist:
@@ -109,7 +112,8 @@ def main():
     sync()
 
     # ---- timed region: exactly K steps ----------------------------------------------------------------
-    ctx.set_stage_timing("fc1_gemm")
+    if not args.graph:
+        ctx.set_stage_timing("fc1_gemm")   # per-launch events would bypass the graph
     barrier(); sync()
     t0 = time.perf_counter()
     ctx.forward_device_async(din.ptr, B, dout.ptr, steps=args.steps)
@@ -164,6 +168,9 @@ def main():
                          "flop_per_launch": fc1_flops, "avg_launch_ms": round(fc1_avg_ms, 5),
                          "min_launch_ms": round(fc1_min_ms, 5), "launches_timed": fc1_n},
         }
+        if args.graph:
+            out["graph"] = True
+            out["roofline"] = None   # no per-launch events inside a replayed graph
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
         if host_path:

@@ -158,6 +158,14 @@ int vh_ring_input(vh_ctx* ctx, float** pinned_in_nhwc);
 int vh_ring_submit(vh_ctx* ctx, const float* in_nhwc_host, int batch);
 int vh_ring_collect(vh_ctx* ctx, float* logits_host, int* batch);
 
+/* hipGraph replay.  With enable != 0 the launch sequence of a forward is captured once per (input pointer, logits
+ * pointer, batch) and replayed with hipGraphLaunch; the first forward at a given batch size still runs eagerly.
+ * Results are bit-identical.  This is for small batches, which are launch-bound (ViT-B/16, batch 1: ~100 launches);
+ * at batch 512 it changes nothing.  Stage timing (vh_set_stage_timing) bypasses the graph.  Environment default:
+ * VH_GRAPH=1.  Counterpart in the reference: none (one clEnqueueTask per forward, netFPGA.cpp:275). */
+int vh_set_graph(vh_ctx* ctx, int enable);
+int vh_get_graph(const vh_ctx* ctx, int* enabled, int* cached_graphs);
+
 /* Concurrency inside one forward: the batch is split into `n` contiguous parts (1..4, default 1, environment
  * VH_STREAMS) that are enqueued on separate streams and joined at the end of every forward.  Images are
  * independent, so the logits are bit-identical for every n; with n = 2 the HBM-bound stages and the partly

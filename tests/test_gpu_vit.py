@@ -229,6 +229,48 @@ def test_ring_pipelined_submit_collect_is_fifo_and_equals_forward():
     ctx.close()
 
 
+def test_graph_replay_is_bit_identical_to_eager_launches():
+    # vh_set_graph: the launch sequence is captured once per (input, output, batch) and replayed; the first forward
+    # at a batch size runs eagerly, the second is captured, later ones replay.  Same bits in every case, for the
+    # host path, the device path, concurrent parts and the ring.
+    cfg = S.CONFIGS["vit_tiny"]
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_BF16, max_batch=4)
+    ctx.load_weights(S.make_blob(cfg, 1))
+    imgs = {b: S.make_images(cfg, 20 + b, b) for b in (1, 3, 4)}
+    want = {b: ctx.forward(imgs[b]) for b in imgs}
+    ctx.set_graph(True)
+    assert ctx.get_graph() == (True, 0)
+    for rep in range(4):
+        for b in (1, 3, 4, 1):
+            assert np.array_equal(ctx.forward(imgs[b]), want[b]), (rep, b)
+    on, cached = ctx.get_graph()
+    assert on and cached == 3                                   # one graph per batch size on the host path
+    other = S.make_images(cfg, 99, 3)
+    assert np.array_equal(ctx.forward(other), vithip_eager(cfg, other))   # new data through the same graph
+    din, dout = vithip.DeviceBuffer.from_numpy(imgs[4]), vithip.DeviceBuffer(4 * cfg["classes"] * 4)
+    for _ in range(3):
+        ctx.forward_device(din.ptr, 4, dout.ptr)
+        assert np.array_equal(dout.to_numpy(np.float32, want[4].shape), want[4])
+    ctx.set_streams(2)                                          # drops the graphs; parts fork/join inside the capture
+    for _ in range(3):
+        assert np.array_equal(ctx.forward(imgs[3]), want[3])
+    ctx.ring_create(2, 4)
+    for _ in range(3):
+        ctx.ring_submit(imgs[4]); ctx.ring_submit(imgs[1])
+        assert np.array_equal(ctx.ring_collect(), want[4]) and np.array_equal(ctx.ring_collect(), want[1])
+    ctx.set_graph(False)
+    assert ctx.get_graph() == (False, 0) and np.array_equal(ctx.forward(imgs[3]), want[3])
+    ctx.close()
+
+
+def vithip_eager(cfg, images):
+    c = vithip.VitContext(cfg, dtype=vithip.DTYPE_BF16, max_batch=len(images))
+    c.load_weights(S.make_blob(cfg, 1))
+    out = c.forward(images)
+    c.close()
+    return out
+
+
 def test_device_resident_path_equals_host_path():
     cfg = S.CONFIGS["vit_mini"]
     batch = 4

@@ -172,6 +172,12 @@ struct vh_ctx {
     std::vector<RingSlot> ring;
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     int ring_batch = 0, ring_wr = 0, ring_rd = 0, ring_used = 0;
+    // optional hipGraph replay of the forward's launch sequence (vh_set_graph): one instantiated graph per
+    // (input pointer, logits pointer, batch); a batch size runs eagerly once before it is captured
+    bool use_graph = false;
+    struct GraphEntry { const float* in; float* out; int batch; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    std::vector<int> graph_warm;   // batch sizes that have run eagerly (kernel attributes are set)
     // optional per-launch timing of ONE stage inside the timed region (bench.py's roofline)
     int timing_stage = -1;
     std::vector<hipEvent_t> tev;  // pool: pairs (start, stop)
@@ -471,6 +477,45 @@ int enqueue_step(vh_ctx* c, const float* in, int batch, float* logits) {
     return enqueue_forward(c, in, batch, logits, nullptr, c->stream, 0);
 }
 
+void drop_graphs(vh_ctx* c) {
+    for (auto& g : c->graphs) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+    }
+    c->graphs.clear();
+}
+
+// enqueue_step, or the replay of its captured launch sequence.  Small batches are launch-bound (ViT-B/16 at
+// batch 1: ~100 launches, 1.27 ms eager): the graph removes the per-launch API cost and the gaps between kernels.
+int run_step(vh_ctx* c, const float* in, int batch, float* logits) {
+    if (!c->use_graph || c->timing_stage >= 0) return enqueue_step(c, in, batch, logits);
+    for (auto& g : c->graphs)
+        if (g.in == in && g.out == logits && g.batch == batch) {
+            HIPCHK(&c->err, hipGraphLaunch(g.exec, c->stream));
+            c->last_batch = batch;
+            return VH_OK;
+        }
+    bool warm = false;
+    for (int b : c->graph_warm) warm |= b == batch;
+    if (!warm) {  // first forward at this batch size: eager, so every kernel it uses has its attributes set
+        c->graph_warm.push_back(batch);
+        return enqueue_step(c, in, batch, logits);
+    }
+    if (c->graphs.size() >= 128) drop_graphs(c);
+    vh_ctx::GraphEntry g{in, logits, batch, nullptr, nullptr};
+    HIPCHK(&c->err, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_step(c, in, batch, logits);
+    const hipError_t e = hipStreamEndCapture(c->stream, &g.graph);   // always close the capture
+    if (rc) { if (g.graph) hipGraphDestroy(g.graph); return rc; }
+    if (e != hipSuccess) return fail(&c->err, VH_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    const hipError_t ei = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess) { hipGraphDestroy(g.graph); return fail(&c->err, VH_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ei)); }
+    c->graphs.push_back(g);
+    HIPCHK(&c->err, hipGraphLaunch(g.exec, c->stream));
+    c->last_batch = batch;
+    return VH_OK;
+}
+
 int check_forward_args(vh_ctx* c, const void* in, int batch, const void* out) {
     if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
     if (!in || !out) return fail(&c->err, VH_ERR_INVALID, "null buffer");
@@ -569,6 +614,10 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         if (c->nstreams < 1) c->nstreams = 1;
         if (c->nstreams > vh_ctx::kMaxStreams) c->nstreams = vh_ctx::kMaxStreams;
     }
+    {
+        const char* e = getenv("VH_GRAPH");
+        c->use_graph = e && e[0] == '1';
+    }
     CK(hipEventCreate(&c->ev0));
     CK(hipEventCreate(&c->ev1));
     // canonical blob
@@ -630,6 +679,7 @@ int vh_destroy(vh_ctx* c) {
     hipSetDevice(c->device);
     vh_ring_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
+    drop_graphs(c);
     if (c->arena) hipFree(c->arena);
     if (c->w16) hipFree(c->w16);
     if (c->blob) hipFree(c->blob);
@@ -819,7 +869,7 @@ int vh_forward_device_async(vh_ctx* c, const float* in, int batch, float* logits
     c->tev_used = 0;
     HIPCHK(&c->err, hipEventRecord(c->ev0, c->stream));
     for (int i = 0; i < steps; ++i)
-        if ((rc = enqueue_step(c, in, batch, logits))) return rc;
+        if ((rc = run_step(c, in, batch, logits))) return rc;
     HIPCHK(&c->err, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return VH_OK;
@@ -996,7 +1046,7 @@ int vh_ring_submit(vh_ctx* c, const float* in_host, int batch) {
     HIPCHK(&c->err, hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, c->copy_in));
     HIPCHK(&c->err, hipEventRecord(s.in_done, c->copy_in));
     HIPCHK(&c->err, hipStreamWaitEvent(c->stream, s.in_done, 0));
-    int rc = enqueue_step(c, s.d_in, batch, s.d_out);
+    int rc = run_step(c, s.d_in, batch, s.d_out);
     if (rc) return rc;
     HIPCHK(&c->err, hipEventRecord(s.fwd_done, c->stream));
     HIPCHK(&c->err, hipStreamWaitEvent(c->copy_out, s.fwd_done, 0));
@@ -1027,6 +1077,23 @@ int vh_set_streams(vh_ctx* c, int n) {
     HIPCHK(&c->err, hipSetDevice(c->device));
     HIPCHK(&c->err, hipStreamSynchronize(c->stream));
     c->nstreams = n;
+    drop_graphs(c);
+    return VH_OK;
+}
+
+int vh_set_graph(vh_ctx* c, int enable) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    c->use_graph = enable != 0;
+    if (!c->use_graph) drop_graphs(c);
+    return VH_OK;
+}
+
+int vh_get_graph(const vh_ctx* c, int* enabled, int* cached) {
+    if (!c || !enabled) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *enabled = c->use_graph ? 1 : 0;
+    if (cached) *cached = (int)c->graphs.size();
     return VH_OK;
 }
 
@@ -1090,6 +1157,8 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
 int vh_debug_set_layers(vh_ctx* c, int n_layers) {
     if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
     c->run_layers = n_layers;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    drop_graphs(c);
     return VH_OK;
 }
 

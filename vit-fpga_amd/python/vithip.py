@@ -80,6 +80,8 @@ SYMBOLS = {
     "vh_ring_input": (_i, [_vp, C.POINTER(C.POINTER(C.c_float))]),
     "vh_ring_submit": (_i, [_vp, _vp, _i]),
     "vh_ring_collect": (_i, [_vp, _vp, _pi]),
+    "vh_set_graph": (_i, [_vp, _i]),
+    "vh_get_graph": (_i, [_vp, _pi, _pi]),
     "vh_set_streams": (_i, [_vp, _i]),
     "vh_get_streams": (_i, [_vp, _pi]),
     "vh_set_stage_timing": (_i, [_vp, _i]),
@@ -361,6 +363,14 @@ class VitContext:
         nb = C.c_int(0)
         _check(lib().vh_ring_collect(self.h, out.ctypes.data, C.byref(nb)), self.h)
         return out[:nb.value]
+
+    def set_graph(self, enable=True):
+        _check(lib().vh_set_graph(self.h, 1 if enable else 0), self.h)
+
+    def get_graph(self):
+        a, b = C.c_int(0), C.c_int(0)
+        _check(lib().vh_get_graph(self.h, C.byref(a), C.byref(b)), self.h)
+        return bool(a.value), b.value
 
     def set_streams(self, n):
         _check(lib().vh_set_streams(self.h, n), self.h)
