@@ -229,6 +229,25 @@ def test_ring_pipelined_submit_collect_is_fifo_and_equals_forward():
     ctx.close()
 
 
+def test_tail_overlap_split_launch_is_bit_identical(monkeypatch):
+    # VH_TAIL_OVERLAP=1: residual GEMMs are launched as [full rounds of tiles] + [tail round] and the LayerNorm of the
+    # finished rows runs beside the tail round on a helper stream.  Needs more tiles than CUs, i.e. a large batch.
+    cfg = S.CONFIGS["vit_mini"]                     # 37 tokens, dim 192: tiles_n = 1
+    B = 2200                                        # 81 400 rows = 318 M-tiles > 256 CUs, 62 in the tail round
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VH_TAIL_OVERLAP", flag)
+        ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_BF16, max_batch=B)
+        ctx.init_weights_seeded(4)
+        din = vithip.DeviceBuffer(B * 96 * 96 * 3 * 4)
+        dout = vithip.DeviceBuffer(B * cfg["classes"] * 4)
+        ctx.fill_input_seeded(5, B, din.ptr)
+        ctx.forward_device(din.ptr, B, dout.ptr)
+        outs[flag] = dout.to_numpy(np.float32, (B, cfg["classes"]))
+        ctx.close()
+    assert np.isfinite(outs["0"]).all() and np.array_equal(outs["0"], outs["1"])
+
+
 def test_graph_replay_is_bit_identical_to_eager_launches():
     # vh_set_graph: the launch sequence is captured once per (input, output, batch) and replayed; the first forward
     # at a batch size runs eagerly, the second is captured, later ones replay.  Same bits in every case, for the

@@ -212,6 +212,7 @@ const char* gemm_check(const GemmArgs& g) {
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (gemm_check(g)) return hipErrorInvalidValue;
     const int variant = g.variant ? g.variant : gemm_pick_variant(g.M, g.N);
+    if ((g.tile_count || g.tile_begin) && variant != 5 && variant != 7) return hipErrorInvalidValue;  // tile ranges: ping-pong forms only
     return g.dtype == VH_DTYPE_BF16 ? launch_epi<BF16>(g, variant, s) : launch_epi<FP16>(g, variant, s);
 }
 

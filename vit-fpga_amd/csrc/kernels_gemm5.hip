@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                   const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
-                  void* __restrict__ out16, float* __restrict__ partials) {
+                  void* __restrict__ out16, float* __restrict__ partials, int tile0) {
     using vec8 = typename T::vec8;
     constexpr int BM = 256, BN = 256;
     constexpr int KT_BYTES = 128;                  // one K-tile row: 64 16-bit or 128 8-bit elements
@@ -85,8 +85,10 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int ntiles = tiles_m * tiles_n;
-    const int stride = PERSIST ? (int)gridDim.x : ntiles;
-    int t = xcd_remap(blockIdx.x, stride);
+    // one tile per workgroup: the grid covers tiles [tile0, tile0 + gridDim.x) of the n-fastest tile order (a launch
+    // may cover a sub-range: GemmArgs::tile_begin / tile_count); persistent: tile0 == 0, stride = grid
+    const int stride = (int)gridDim.x;
+    int t = tile0 + xcd_remap(blockIdx.x, stride);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -314,14 +316,20 @@ static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int ti
         attr_done = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
-                       tiles_n, g.stats, g.out16, g.partials);
+                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin);
     return hipGetLastError();
 }
 
 template <typename T, int EPI, bool F8>
 static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
     const int tiles_m = (int)((g.M + 255) / 256), tiles_n = (g.N + 255) / 256;
-    const int ntiles = tiles_m * tiles_n;
+    int ntiles = tiles_m * tiles_n;
+    if (g.tile_count > 0) {   // a sub-range of the tiles (one tile per workgroup forms only)
+        if (mode == 1 || g.tile_begin < 0 || g.tile_begin + g.tile_count > ntiles) return hipErrorInvalidValue;
+        ntiles = g.tile_count;
+    } else if (g.tile_begin != 0) {
+        return hipErrorInvalidValue;
+    }
     if (mode == 2) return launch_pp_one<T, EPI, F8, false, 3>(g, ntiles, tiles_m, tiles_n, s);
     if constexpr (!F8) {
         if (mode == 1) {

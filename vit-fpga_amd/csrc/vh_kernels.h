@@ -20,6 +20,10 @@ struct GemmArgs {
     const float* stats = nullptr;  // LNFOLD*: [M][2] (mean, rstd)
     void* out16 = nullptr;         // RESID_LN: 16-bit copy of the updated rows
     float* partials = nullptr;     // RESID_LN: [N/64][M][2]
+    // ping-pong forms 5 / 7 only: launch tiles [tile_begin, tile_begin + tile_count) of the n-fastest 256x256 tile order
+    // (tile t = (t / tiles_n, t % tiles_n)); tile_count == 0 = all tiles.  Lets a caller split off the last, partly
+    // filled round of tiles and overlap it with other work (vithip_api.hip, tail overlap).
+    int tile_begin = 0, tile_count = 0;
 };
 
 // every launcher only enqueues on `stream`; returns hipSuccess or the launch error
