@@ -91,6 +91,7 @@ int vh_free(int device, void* dev_ptr);
 int vh_memcpy_h2d(int device, void* dev_dst, const void* host_src, size_t nbytes);
 int vh_memcpy_d2h(int device, void* host_dst, const void* dev_src, size_t nbytes);
 int vh_device_synchronize(int device);
+int vh_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo */
 
 /* ---- ViT context ---------------------------------------------------------------------- */
 /* replaces _init_program + _init_kernel(const char*) (netFPGA.cpp:367-441): device,

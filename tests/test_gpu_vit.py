@@ -290,6 +290,36 @@ def vithip_eager(cfg, images):
     return out
 
 
+def test_contexts_can_be_created_and_destroyed_repeatedly():
+    # no leaked device memory / streams / events across create-use-destroy cycles (incl. ring, graphs, filter ring)
+    cfg = S.CONFIGS["vit_micro"]
+    blob, images = S.make_blob(cfg, 8), S.make_images(cfg, 9, 2)
+    first = None
+    free0 = None
+    for i in range(12):
+        ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16 if i % 2 else vithip.DTYPE_BF16, max_batch=2)
+        ctx.load_weights(blob)
+        ctx.set_graph(i % 3 == 0)
+        ctx.ring_create(2, 2)
+        ctx.ring_submit(images)
+        got = ctx.ring_collect()
+        got2 = ctx.forward(images)
+        assert np.array_equal(got, got2)
+        if i == 1:
+            first = got
+        if i % 2 and i > 1:
+            assert np.array_equal(got, first)
+        f = vithip.FilterPipeline(32, 48, slots=3)
+        f.submit(np.zeros((32, 48), np.uint8)); f.collect(); f.close()
+        ctx.close()
+        free = vithip.device_free_bytes()
+        if i == 2:
+            free0 = free
+        if i > 2:
+            assert free >= free0 - (64 << 20), (i, free0, free)   # allow allocator slack, catch per-cycle leaks
+    assert first is not None
+
+
 def test_device_resident_path_equals_host_path():
     cfg = S.CONFIGS["vit_mini"]
     batch = 4

@@ -277,12 +277,8 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     const bool persist = want_persist && 2 * one <= 160 * 1024 && nitems > num_cu;
     if constexpr (!std::is_same<T, TO>::value) {
         auto k = attention_kernel<T, false, TO>;
-        static size_t lds_max = 0;
-        if (one > lds_max) {
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)one);
-            if (e != hipSuccess) return e;
-            lds_max = one;
-        }
+        static int lds_done[kMaxDevices] = {0};
+        if (hipError_t e = ensure_dynamic_lds((const void*)k, one, lds_done); e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(nitems), dim3(nw * 64), one, s, (const typename T::elem*)qkv, (typename TO::elem*)out,
                            tokens, heads, slabs, ntiles, nitems);
         return hipGetLastError();
@@ -290,12 +286,8 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     if (persist) {
         const size_t lds = 2 * one;
         auto k = attention_kernel<T, true>;
-        static size_t lds_max = 0;
-        if (lds > lds_max) {
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            lds_max = lds;
-        }
+        static int lds_done[kMaxDevices] = {0};
+        if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
         const int per_cu = (int)(160 * 1024 / lds);   // co-resident workgroups per CU by LDS
         int grid = num_cu * (per_cu < 1 ? 1 : per_cu);
         if (grid > nitems) grid = nitems;
@@ -303,12 +295,8 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
                            tokens, heads, slabs, ntiles, nitems);
     } else {
         auto k = attention_kernel<T, false>;
-        static size_t lds_max = 0;
-        if (one > lds_max) {
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)one);
-            if (e != hipSuccess) return e;
-            lds_max = one;
-        }
+        static int lds_done[kMaxDevices] = {0};
+        if (hipError_t e = ensure_dynamic_lds((const void*)k, one, lds_done); e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(nitems), dim3(nw * 64), one, s, (const typename T::elem*)qkv, (typename T::elem*)out,
                            tokens, heads, slabs, ntiles, nitems);
     }

@@ -141,12 +141,8 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
     const int tiles_m = (int)((g.M + BM - 1) / BM), tiles_n = (g.N + BN - 1) / BN;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
     auto k = gemm_nt_kernel<T, BM, BN, WM, WN, EPI>;
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static int lds_done[kMaxDevices] = {0};  // per instantiation, per device
+    if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, s,
                        (const typename T::elem*)g.a, (const typename T::elem*)g.w, g.bias, g.out,
                        (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n, g.stats, g.out16, g.partials);

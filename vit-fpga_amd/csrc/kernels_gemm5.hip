@@ -309,12 +309,8 @@ template <typename T, int EPI, bool F8, bool PERSIST, int AST>
 static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int tiles_n, hipStream_t s) {
     constexpr size_t lds = AST == 3 ? 163840 : 131072;
     auto k = gemm_nt_pp_kernel<T, EPI, PERSIST, F8, AST>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static int lds_done[kMaxDevices] = {0};  // per instantiation, per device
+    if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
                        tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin);
     return hipGetLastError();

@@ -395,7 +395,6 @@ hipError_t launch_fold_ln(const float* w, const float* b, const float* gamma, co
     return hipGetLastError();
 }
 
-hipError_t init_kernel_attributes() { return hipSuccess; }
 
 // ---- 3x3 image filter on 8-bit single-channel frames (the reference's filter_image pipeline) --------------------
 // The reference's kernel `image_process` is absent (netFPGA.cpp:305 names it, no source, no bitstream), so its

@@ -71,6 +71,18 @@ hipError_t launch_dense_layer(const float* w, const float* b, const float* x, fl
 // 3x3 filter on 8-bit frames (filter_image): kind 0 = binomial blur, 1 = Sobel |gx|+|gy|
 hipError_t launch_filter3x3(const uint8_t* in, uint8_t* out, int h, int w, int kind, hipStream_t stream);
 
-hipError_t init_kernel_attributes();  // opt in to >64 KiB dynamic LDS, once per process
+// Opt a kernel in to `bytes` of dynamic LDS on the CURRENT device.  The attribute is per device, so the record of
+// what has been set is too: `done[d]` = bytes already granted on device d (one array per kernel instantiation).
+constexpr int kMaxDevices = 64;
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, int (&done)[kMaxDevices]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    if ((size_t)done[dev] >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done[dev] = (int)bytes;
+    return e;
+}
 
 }  // namespace vh

@@ -586,6 +586,13 @@ int vh_memcpy_d2h(int device, void* h, const void* d, size_t n) {
     HIPCHK(nullptr, hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
     return VH_OK;
 }
+int vh_device_mem_info(int device, size_t* free_bytes, size_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    int rc = set_device(nullptr, device);
+    if (rc) return rc;
+    HIPCHK(nullptr, hipMemGetInfo(free_bytes, total_bytes));
+    return VH_OK;
+}
 int vh_device_synchronize(int device) {
     int rc = set_device(nullptr, device);
     if (rc) return rc;

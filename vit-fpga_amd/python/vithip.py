@@ -71,6 +71,7 @@ SYMBOLS = {
     "vh_filter_submit": (_i, [_vp, _vp]),
     "vh_filter_collect": (_i, [_vp, _vp]),
     "vh_filter_last_error": (C.c_char_p, [_vp]),
+    "vh_device_mem_info": (_i, [_i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "vh_blob_file_config": (_i, [C.c_char_p, C.POINTER(Config)]),
     "vh_save_weights_file": (_i, [_vp, C.c_char_p]),
     "vh_load_weights_file": (_i, [_vp, C.c_char_p]),
@@ -145,6 +146,12 @@ def blob_file_config(path):
     c = Config()
     _check(lib().vh_blob_file_config(os.fsencode(path), C.byref(c)))
     return {k: getattr(c, k) for k in ("image_size", "patch_size", "channels", "dim", "heads", "mlp_dim", "layers", "classes")}, c.ln_eps
+
+
+def device_free_bytes(device=0):
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    _check(lib().vh_device_mem_info(device, C.byref(free), C.byref(total)))
+    return free.value
 
 
 def make_config(cfg, dtype=DTYPE_BF16, max_batch=1, ln_eps=1e-6):
