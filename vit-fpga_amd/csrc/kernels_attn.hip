@@ -58,7 +58,7 @@ __device__ __forceinline__ float cross_half_sum(float v) {
 }
 
 template <typename T, bool PERSIST, typename TO = T>   // TO: output element (T, or E4M3 on the fp8 path)
-__global__ void __launch_bounds__(512, PERSIST ? 2 : 4)   // one-shot form: <= 128 VGPRs, two 7-wave workgroups per CU put 4 waves on a SIMD
+__global__ void __launch_bounds__(1024, PERSIST ? 2 : 4)   // one-shot form: <= 128 VGPRs, two 7-wave workgroups per CU put 4 waves on a SIMD
 attention_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __restrict__ out,
                  int tokens, int heads, int slabs, int ntiles, int nitems) {
     using elem = typename T::elem;
@@ -257,7 +257,9 @@ template <typename T, typename TO = T>
 static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, hipStream_t s) {
     const int ntiles = (tokens + 31) / 32;
     const int nqb = ntiles;
-    const int slabs = (nqb + 7) / 8;
+    static int max_waves = 0;   // waves per workgroup (each owns 32 queries): VH_ATTN_WAVES, default 16 (T = 577: 10 waves share one K/V image instead of 7)
+    if (!max_waves) { const char* e = getenv("VH_ATTN_WAVES"); max_waves = e ? atoi(e) : 16; if (max_waves < 1 || max_waves > 16) max_waves = 16; }
+    const int slabs = (nqb + max_waves - 1) / max_waves;
     const int nw = (nqb + slabs - 1) / slabs;
     const size_t one = attention_lds_bytes(tokens);
     if (one > 160 * 1024) return hipErrorInvalidValue;
