@@ -31,6 +31,18 @@ def test_header_symbols_are_exported_and_bound():
     assert vithip.lib().vh_abi_version() == 1
 
 
+def test_header_is_plain_c_and_the_c_example_builds(tmp_path):
+    # the boundary is a C ABI: the header must compile as C99 with warnings as errors, and the plain-C example links
+    hdr = os.path.join(ROOT, "include")
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "vithip.h"\nint main(void) { return vh_abi_version() == VH_ABI_VERSION ? 0 : 1; }\n')
+    lib_dir = os.path.dirname(vithip.LIB_PATH)
+    for src, exe in ((str(probe), tmp_path / "probe"), (os.path.join(ROOT, "examples", "classify.c"), tmp_path / "classify")):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", hdr, src, "-L", lib_dir,
+                               "-lvithip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
+    assert subprocess.call([str(tmp_path / "probe")]) == 0
+
+
 def test_no_torch_or_oracle_dependency_in_the_product_library():
     out = subprocess.check_output(["readelf", "-d", vithip.LIB_PATH], text=True)
     needed = re.findall(r"NEEDED.*\[(.*?)\]", out)

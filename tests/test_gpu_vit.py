@@ -320,6 +320,28 @@ def test_contexts_can_be_created_and_destroyed_repeatedly():
     assert first is not None
 
 
+def test_plain_c_example_runs_and_agrees_with_the_python_binding(tmp_path):
+    import re
+    import subprocess
+    root = os.path.dirname(HERE)
+    lib_dir = os.path.dirname(vithip.LIB_PATH)
+    exe = tmp_path / "classify"
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "classify.c"),
+                           "-L", lib_dir, "-lvithip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
+    cfg = S.CONFIGS["vit_base"]
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_BF16, max_batch=2)
+    ctx.init_weights_seeded(0)
+    want = ctx.forward(S.make_images(cfg, 1, 2))
+    path = tmp_path / "b16.vhblob"
+    ctx.save_weights_file(path)
+    ctx.close()
+    for arg in ("-", str(path)):                                  # seeded weights, then the same weights from a file
+        out = subprocess.check_output([str(exe), arg, "2"], text=True)
+        got = [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"class (\d+) \(logit ([-0-9.]+)\)", out)]
+        assert [g[0] for g in got] == list(want.argmax(1)), out
+        assert np.allclose([g[1] for g in got], want.max(1), atol=1e-4)
+
+
 def test_device_resident_path_equals_host_path():
     cfg = S.CONFIGS["vit_mini"]
     batch = 4
