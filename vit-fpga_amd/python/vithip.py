@@ -264,6 +264,7 @@ class VitContext:
         h = C.c_void_p()
         _check(lib().vh_create(C.byref(self.c), device, C.byref(h)))
         self.h = h.value
+        self._ring_batch = 0
 
     def close(self):
         if self.h:
@@ -366,7 +367,7 @@ class VitContext:
             _check(lib().vh_ring_submit(self.h, images.ctypes.data, images.shape[0]), self.h)
 
     def ring_collect(self):
-        out = np.empty((self._ring_batch, self.cfg["classes"]), dtype=np.float32)
+        out = np.empty((max(self._ring_batch, 1), self.cfg["classes"]), dtype=np.float32)
         nb = C.c_int(0)
         _check(lib().vh_ring_collect(self.h, out.ctypes.data, C.byref(nb)), self.h)
         return out[:nb.value]
