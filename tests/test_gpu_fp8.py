@@ -90,6 +90,31 @@ def test_gemm_fp32_out_matches_fp32_accumulation(M, N, K, variant):
     assert np.abs(got - (x0 + ref)).max() <= 2e-5 * max(scale, 1.0)
 
 
+def test_gemm_random_ragged_shapes_with_canary_rows():
+    rng = np.random.default_rng(5)
+    for i in range(10):
+        M, N, K = int(rng.integers(1, 701)), 4 * int(rng.integers(1, 276)), 128 * int(rng.integers(1, 9))
+        a, a8, w8, wq, sc, bias = _operands(M, N, K, 70 + i)
+        pre = O.linear(a, wq) * sc[None, :] + bias[None, :]
+        if i % 2 == 0:
+            x0 = S.fill((M + 2) * N, 80 + i, 4, 0).reshape(M + 2, N)
+            buf = dev(x0)
+            vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, buf.ptr + N * 4, M, N, K, vithip.EPI_BIAS_RESID,
+                               5 + 2 * (i % 4 == 0))
+            got = buf.to_numpy(np.float32, (M + 2, N))
+            assert np.array_equal(got[0], x0[0]) and np.array_equal(got[-1], x0[-1]), (M, N, K)
+            assert np.abs(got[1:-1] - (x0[1:-1] + pre)).max() <= 2e-5 * max(np.abs(pre).max(), 1.0), (M, N, K)
+        else:
+            canary = np.full((M + 2, N), 0x7B, np.uint8)
+            buf = dev(canary)
+            vithip.op_gemm_fp8(dev(a8).ptr, dev(w8).ptr, dev(sc).ptr, dev(bias).ptr, buf.ptr + N, M, N, K, vithip.EPI_BIAS_GELU)
+            raw = buf.to_numpy(np.uint8, (M + 2, N))
+            assert (raw[0] == 0x7B).all() and (raw[-1] == 0x7B).all(), (M, N, K)
+            got8, want8 = vithip.from_e4m3(raw[1:-1]), O.quant_e4m3(O.gelu(pre))
+            step = np.maximum(np.abs(want8), 2.0 ** -6) * 2.0 ** -3 + 1e-12
+            assert np.all(np.abs(got8 - want8) <= step * 1.001), (M, N, K)
+
+
 def test_gemm_integer_exact_asymmetric():
     # small integers and halves are exact in e4m3 and in the fp32 accumulator: any lane-map mistake shows
     M, N, K = 272, 264, 256

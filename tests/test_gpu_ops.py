@@ -130,6 +130,40 @@ def test_gemm_bias_f32(dt, variant, M, N, K):
     assert np.abs(got - ref).max() <= 2e-5 * scale, np.abs(got - ref).max() / scale
 
 
+def _random_shapes(n, seed, kstep):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 701)), 4 * int(rng.integers(1, 276)), kstep * int(rng.integers(1, 1024 // kstep + 1))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("variant", [1, 5, 7])
+def test_gemm_random_ragged_shapes_with_canary_rows(variant):
+    # 16 seeded random (M, N, K): every epilogue class on shapes no tile divides, and the output buffer carries one
+    # extra row of canaries on each side that no store may touch
+    for i, (M, N, K) in enumerate(_random_shapes(16, 100 + variant, 64)):
+        dt = DT[i % 2]
+        a = rnd16(S.fill(M * K, 30 + i, 1, 0).reshape(M, K), dt)
+        w = rnd16(S.fill(N * K, 30 + i, 2, 1, 0.05).reshape(N, K), dt)
+        bias = S.fill(N, 30 + i, 3, 1, 0.1)
+        pre = O.linear(a, w, bias)
+        A, W, Bv = dev(vithip.to16(a, dt)), dev(vithip.to16(w, dt)), dev(bias)
+        if i % 3 == 0:      # fp32 out, residual form
+            x0 = S.fill((M + 2) * N, 60 + i, 4, 0).reshape(M + 2, N)
+            buf = dev(x0)
+            vithip.op_gemm(A.ptr, W.ptr, Bv.ptr, buf.ptr + N * 4, M, N, K, vithip.EPI_BIAS_RESID, dt, variant=variant)
+            got = buf.to_numpy(np.float32, (M + 2, N))
+            assert np.array_equal(got[0], x0[0]) and np.array_equal(got[-1], x0[-1]), (M, N, K)
+            assert np.abs(got[1:-1] - (x0[1:-1] + pre)).max() <= 2e-5 * max(np.abs(pre).max(), 1.0), (M, N, K)
+        else:               # 16-bit out, plain or GELU
+            gelu = i % 3 == 2
+            canary = np.full((M + 2, N), 0x7B7B, np.uint16)
+            buf = dev(canary)
+            vithip.op_gemm(A.ptr, W.ptr, Bv.ptr, buf.ptr + N * 2, M, N, K, vithip.EPI_BIAS_GELU if gelu else vithip.EPI_BIAS, dt,
+                           variant=variant)
+            raw = buf.to_numpy(np.uint16, (M + 2, N))
+            assert (raw[0] == 0x7B7B).all() and (raw[-1] == 0x7B7B).all(), (M, N, K)
+            assert_close16(vithip.from16(raw[1:-1], dt), O.gelu(pre) if gelu else pre, dt, extra=4e-5 * np.abs(pre).max())
+
+
 @pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_integer_exact_asymmetric(dt, variant):
