@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
-LIB_PATH = os.path.join(PKG_ROOT, "libvithip.so")
+LIB_PATH = os.environ.get("VITHIP_LIB") or os.path.join(PKG_ROOT, "libvithip.so")   # VITHIP_LIB: A/B builds (tools/)
 
 DTYPE_BF16, DTYPE_FP16, DTYPE_FP8 = 0, 1, 2
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH, EPI_LNFOLD, EPI_LNFOLD_GELU, EPI_RESID_LN = range(8)
