@@ -44,6 +44,8 @@
 //      L1: X fragments of row blocks 4-7                   C1: 16 MFMAs (row blocks 4-7)
 // (same 512 matrix cycles per phase, same 64 fragment registers).  W carries one fp32 scale per output channel
 // (`aux`), applied to the accumulators before the epilogue; activations are unscaled (vh_common.h, E4M3).
+#include <cstdlib>
+
 #include "gemm_epilogue.h"
 #include "vh_kernels.h"
 
@@ -72,7 +74,7 @@ __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                   const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
-                  void* __restrict__ out16, float* __restrict__ partials, int tile0) {
+                  void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn) {
     using vec8 = typename T::vec8;
     constexpr int BM = 256, BN = 256;
     constexpr int KT_BYTES = 128;                  // one K-tile row: 64 16-bit or 128 8-bit elements
@@ -103,8 +105,18 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     const char *gA[4], *gW[4];
     int tile_m = 0, tile_n = 0;
     auto setup_tile = [&](int tt) {
-        tile_m = tt / tiles_n;
-        tile_n = tt - tile_m * tiles_n;
+        // Tile order.  sn == 0: n fastest over all tiles_n column tiles.  sn > 0: super-columns of sn column tiles, m
+        // fastest-but-one inside each: the workgroups of an XCD then share sn W panels (which stay in its 4 MiB L2
+        // from round to round) instead of all tiles_n (fc1: 12 panels = 4.7 MB, re-fetched from beyond L2 every round).
+        if (sn > 0) {
+            const int blk = tiles_m * sn, sc = tt / blk, r = tt - sc * blk;
+            const int width = tiles_n - sc * sn < sn ? tiles_n - sc * sn : sn;
+            tile_m = r / width;
+            tile_n = sc * sn + (r - tile_m * width);
+        } else {
+            tile_m = tt / tiles_n;
+            tile_n = tt - tile_m * tiles_n;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = grp * 128 + (i * 4 + wn) * 8 + lr;
@@ -308,6 +320,19 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     }
 }
 
+// super-column width of the tile order for a GEMM with `tiles_n` column tiles (0 = plain n-fastest); VH_PP_SN overrides
+static int gemm_super_columns(int tiles_n) {
+    static int env = -2;   // -1 = automatic
+    if (env == -2) { const char* e = getenv("VH_PP_SN"); env = e ? atoi(e) : -1; if (env < -1) env = -1; }
+    if (env >= 0) return env > 0 && env < tiles_n ? env : 0;
+    // measured on ViT-B/16 b512 (tools/ab_supercol.sh): 9 column tiles (q|k|v) best at 3, 12 (fc1) at 4; 3 (proj, fc2)
+    // need none.  Widths that divide tiles_n keep every super-column full.
+    if (tiles_n < 6) return 0;
+    if (tiles_n % 4 == 0) return 4;
+    if (tiles_n % 3 == 0) return 3;
+    return 4;
+}
+
 // mode 0: one tile per workgroup (variant 5); 1: persistent (6); 2: one tile per workgroup, three A stages (7)
 template <typename T, int EPI, bool F8, bool PERSIST, int AST>
 static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int tiles_n, hipStream_t s) {
@@ -316,7 +341,7 @@ static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int ti
     static int lds_done[kMaxDevices] = {0};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
-                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin);
+                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n));
     return hipGetLastError();
 }
 
