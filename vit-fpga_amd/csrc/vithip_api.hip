@@ -666,10 +666,11 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     w16_bytes += align_up((size_t)cfg->layers * 3 * D * 4, 256);
     {
         const char* e = getenv("VH_LN_FOLD");
-        // Opt-in (VH_LN_FOLD=1).  Measured on ViT-B/16 b512: the 24 stand-alone LayerNorm launches (1.94 ms, at the
-        // HBM roofline) disappear, but the RESID_LN / LNFOLD epilogues sit on every tile's critical path and cost
-        // 2.3 ms more than the plain ones -> 24.7 ms vs 24.4 ms per step.  Kept for shapes where it pays.
-        c->ln_fold = (cfg->dim % 256 == 0) && (cfg->mlp_dim % 256 == 0) && (e && e[0] == '1');
+        // LayerNorm folded into the neighbouring GEMMs, on by default where the shapes allow it (VH_LN_FOLD=0 selects the
+        // stand-alone kernel).  ViT-B/16 b512: the 24 LayerNorm launches (1.99 ms at the HBM roofline: 11 GB of the
+        // forward's traffic) disappear; the RESID_LN / LNFOLD epilogues and the 24 tiny statistics kernels cost 1.1 ms:
+        // 23 270 -> 24 280 images/s.  (When first built, before the cheaper GELU and epilogue changes, it was break-even.)
+        c->ln_fold = (cfg->dim % 256 == 0) && (cfg->mlp_dim % 256 == 0) && !(e && e[0] == '0');
     }
     c->fp8 = cfg->dtype == VH_DTYPE_FP8;
     c->dt16 = c->fp8 ? VH_DTYPE_BF16 : cfg->dtype;
