@@ -149,8 +149,9 @@ def main():
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]  # PMC passes of this command, see that file
         achieved = fc1_flops / (fc1_avg_ms * 1e-3) / 1e12 if fc1_avg_ms > 0 else 0.0
         # LayerNorm is folded into the GEMM epilogues when the library does so (its default for these shapes)
+        env_fold = os.environ.get("VH_LN_FOLD")
         ln_fold = (args.dtype != "fp8" and cfg["dim"] % 256 == 0 and cfg["mlp_dim"] % 256 == 0
-                   and os.environ.get("VH_LN_FOLD", "1") != "0")
+                   and (env_fold == "1" if env_fold is not None else B * T >= 50000))
         peak = PEAK_TFLOPS[args.dtype]
         out = {
             "metric": "images/sec ViT-B/16 224x224, batch 512 per GPU" if args.config == "vit_base" and B == 512 and args.dtype == "bf16"

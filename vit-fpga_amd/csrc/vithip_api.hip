@@ -666,11 +666,14 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     w16_bytes += align_up((size_t)cfg->layers * 3 * D * 4, 256);
     {
         const char* e = getenv("VH_LN_FOLD");
-        // LayerNorm folded into the neighbouring GEMMs, on by default where the shapes allow it (VH_LN_FOLD=0 selects the
-        // stand-alone kernel).  ViT-B/16 b512: the 24 LayerNorm launches (1.99 ms at the HBM roofline: 11 GB of the
-        // forward's traffic) disappear; the RESID_LN / LNFOLD epilogues and the 24 tiny statistics kernels cost 1.1 ms:
-        // 23 270 -> 24 280 images/s.  (When first built, before the cheaper GELU and epilogue changes, it was break-even.)
-        c->ln_fold = (cfg->dim % 256 == 0) && (cfg->mlp_dim % 256 == 0) && !(e && e[0] == '0');
+        // LayerNorm folded into the neighbouring GEMMs.  VH_LN_FOLD=1 / 0 force it on (where the shapes allow) / off;
+        // unset: on for large workloads (>= 50 000 token rows at max_batch).  ViT-B/16 b512: the 24 LayerNorm launches
+        // (1.99 ms at the HBM roofline, 11 GB of the forward's traffic) disappear, the RESID_LN / LNFOLD epilogues and
+        // the 24 statistics kernels cost 1.1 ms: +1.0 ... +4.4 % images/s depending on the box (boxes differ in how hard
+        // the power cap bites); at batch 64-256 it is -0.3 ... -1.2 %, hence the threshold.
+        const bool eligible = (cfg->dim % 256 == 0) && (cfg->mlp_dim % 256 == 0);
+        const bool large = (size_t)cfg->max_batch * (size_t)L.T >= 50000;
+        c->ln_fold = eligible && (e ? e[0] == '1' : large);
     }
     c->fp8 = cfg->dtype == VH_DTYPE_FP8;
     c->dt16 = c->fp8 ? VH_DTYPE_BF16 : cfg->dtype;
