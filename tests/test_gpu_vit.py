@@ -342,6 +342,41 @@ def test_plain_c_example_runs_and_agrees_with_the_python_binding(tmp_path):
         assert np.allclose([g[1] for g in got], want.max(1), atol=1e-4)
 
 
+def test_two_contexts_on_two_host_threads():
+    # per-instance device state (no globals, unlike the reference's namespace-level singletons, netFPGA.cpp:21-56):
+    # distinct contexts are usable from distinct threads at the same time and do not disturb each other
+    import threading
+    cfgs = [S.CONFIGS["vit_tiny"], S.CONFIGS["vit_mini"]]
+    dts = [vithip.DTYPE_BF16, vithip.DTYPE_FP16]
+    data = [(S.make_blob(c, 3 + i), S.make_images(c, 4 + i, 3)) for i, c in enumerate(cfgs)]
+    want = []
+    for (blob, imgs), c, dt in zip(data, cfgs, dts):
+        ctx = vithip.VitContext(c, dtype=dt, max_batch=3)
+        ctx.load_weights(blob)
+        want.append(ctx.forward(imgs))
+        ctx.close()
+    errors = []
+
+    def worker(i):
+        try:
+            ctx = vithip.VitContext(cfgs[i], dtype=dts[i], max_batch=3)
+            ctx.load_weights(data[i][0])
+            for _ in range(25):
+                if not np.array_equal(ctx.forward(data[i][1]), want[i]):
+                    errors.append((i, "logits differ"))
+                    break
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in (0, 1)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 def test_device_resident_path_equals_host_path():
     cfg = S.CONFIGS["vit_mini"]
     batch = 4
