@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time table to stderr")
     ap.add_argument("--host-path", action="store_true",
                     help="also measure the PCIe-inclusive rate through the pinned submit/collect ring (extra object, never `value`)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo + --same-device rehearses the N > 1 control flow on a one-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--graph", action="store_true", help="replay the forward as a hipGraph (small batches are launch-bound)")
     ap.add_argument("--streams", type=int, default=0, help="split every forward into N concurrent parts (0 = library default, 1)")
     args = ap.parse_args()
@@ -59,7 +62,9 @@ def main():
     torch = dist = None
     if use_dist:
         # torch first: its bundled HIP runtime is then the one libvithip.so binds to as well
-        torch, dist = vh_dist.init_process_group("nccl", rank, world, local_rank)
+        if args.same_device:
+            local_rank = 0
+        torch, dist = vh_dist.init_process_group(args.backend, rank, world, local_rank)
 
     import numpy as np
     import vh_synth as S

@@ -24,6 +24,8 @@ def init_process_group(backend, rank, world, local_rank=0):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         kw["device_id"] = torch.device("cuda", local_rank)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)   # gloo rehearsal of the GPU path: tensors still live on the rank's device
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return torch, dist
 
