@@ -171,9 +171,7 @@ int vh_get_graph(const vh_ctx* ctx, int* enabled, int* cached_graphs);
  * VH_STREAMS) that are enqueued on separate streams and joined at the end of every forward.  Images are
  * independent, so the logits are bit-identical for every n; with n = 2 the HBM-bound stages and the partly
  * filled last tile round of one half overlap the MFMA-bound stages of the other (+5 % images/s at ViT-B b512).
- * Off by default: two kernels then share the device, so a per-launch duration no longer measures one kernel.
- * Ignored (vh_get_streams reports 1) while the LayerNorm fold is active -- the default for models whose dim and
- * mlp_dim are multiples of 256, environment VH_LN_FOLD=0 turns it off: its row-statistics buffers are per context. */
+ * Off by default: two kernels then share the device, so a per-launch duration no longer measures one kernel. */
 int vh_set_streams(vh_ctx* ctx, int n);
 int vh_get_streams(const vh_ctx* ctx, int* n);
 

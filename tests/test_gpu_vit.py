@@ -94,6 +94,8 @@ def test_folded_layernorm_path_agrees_with_the_separate_layernorm_path(monkeypat
         ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=2)
         ctx.load_weights(blob)
         outs[fold] = ctx.forward(images)
+        ctx.set_streams(2)                                   # concurrent parts slice the statistics buffers
+        assert ctx.get_streams() == 2 and np.array_equal(ctx.forward(images), outs[fold]), fold
         ctx.close()
         assert rel(outs[fold], ref) <= 1e-3, (fold, rel(outs[fold], ref))
     print(f"\n[fold] fp16 folded vs separate LN: {rel(outs['1'], outs['0']):.3e}")

@@ -299,6 +299,10 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     const size_t r0 = (size_t)img0 * T, esz = 2, esz_op = c->fp8 ? 1 : 2;  // esz_op: GEMM A-operand element
     const int dt16 = c->dt16;
     float* const x = c->x + r0 * D;
+    // LayerNorm-fold row statistics of this part: (mean, rstd) per row, and the [D/64][rows][2] partial sums; parts take
+    // disjoint slices (a part's partial-sum block is (D/64) * rows * 2 floats, laid out for ITS row count)
+    float* const stats_p = c->stats + r0 * 2;
+    float* const partials_p = c->partials + (size_t)(D / 64) * r0 * 2;
     char* const xn16 = (char*)c->xn16 + r0 * D * esz_op;
     char* const qkv16 = (char*)c->qkv16 + r0 * 3 * D * esz;
     char* const att16 = (char*)c->att16 + r0 * D * esz_op;
@@ -316,9 +320,9 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     auto gemm = [&](const void* a, const void* w, const float* bias, void* out, int64_t Mr, int N, int K, int epi,
                     const float* aux, int aux_i) {
         GemmArgs g{a, w, bias, out, Mr, N, K, epi, aux, aux_i, dt16, 0};
-        g.stats = c->stats;        // read by LNFOLD*, ignored otherwise
+        g.stats = stats_p;         // read by LNFOLD*, ignored otherwise
         g.out16 = xn16;            // written by RESID_LN
-        g.partials = c->partials;
+        g.partials = partials_p;
         return launch_gemm(g, s);
     };
     // hip events around every launch of the stage selected by vh_set_stage_timing()
@@ -343,7 +347,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
     if (c->ln_fold && nl > 0) {
         // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
-        HIPCHK(&c->err, launch_rowstats_cast(x, rows, D, f.ln_eps, xn16, c->stats, dt16, s));
+        HIPCHK(&c->err, launch_rowstats_cast(x, rows, D, f.ln_eps, xn16, stats_p, dt16, s));
         if ((rc = mark(ST_LNSTATS))) return rc;
     }
     for (int l = 0; l < nl && c->ln_fold; ++l) {
@@ -362,7 +366,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows, D, D, VH_EPI_RESID_LN, nullptr, 0));
         if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
-        HIPCHK(&c->err, launch_finalize_stats(c->partials, nblk, rows, D, f.ln_eps, c->stats, s));
+        HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows, D, f.ln_eps, stats_p, s));
         if ((rc = mark(ST_LNSTATS))) return rc;
         if ((rc = tmark(ST_FC1))) return rc;
         HIPCHK(&c->err, gemm(xn16, c->w1_16[l], cd + 6 * D + M, h16, rows, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0));
@@ -373,7 +377,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
         if (l + 1 < nl) {
-            HIPCHK(&c->err, launch_finalize_stats(c->partials, nblk, rows, D, f.ln_eps, c->stats, s));
+            HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows, D, f.ln_eps, stats_p, s));
             if ((rc = mark(ST_LNSTATS))) return rc;
         }
     }
@@ -468,7 +472,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
 // from and joined back into c->stream, so everything that follows on c->stream sees the finished logits
 int enqueue_step(vh_ctx* c, const float* in, int batch, float* logits) {
     const size_t img_floats = (size_t)c->cfg.image_size * c->cfg.image_size * c->cfg.channels;
-    const int parts = c->ln_fold ? 1 : (batch < c->nstreams ? batch : c->nstreams);
+    const int parts = batch < c->nstreams ? batch : c->nstreams;
     int rc;
     if (parts > 1) {
         // contiguous parts of the batch on different streams: the HBM-bound stages and the partly filled
@@ -1139,7 +1143,7 @@ int vh_get_graph(const vh_ctx* c, int* enabled, int* cached) {
 
 int vh_get_streams(const vh_ctx* c, int* n) {
     if (!c || !n) return fail(nullptr, VH_ERR_INVALID, "null argument");
-    *n = c->ln_fold ? 1 : c->nstreams;
+    *n = c->nstreams;
     return VH_OK;
 }
 
