@@ -166,6 +166,29 @@ def test_full_size_batch_512_properties():
     ctx.close()
 
 
+def test_batch_4096_crosses_the_2_to_31_element_mark():
+    # BASELINE config 3's global batch on ONE device: 806 912 token rows; the MLP hidden tensor has 2.48e9 elements,
+    # so every row * width product in the kernels must be 64-bit.  Checked through batch independence: images from
+    # the far end of the batch, run alone, must reproduce their rows of the big run bit for bit.
+    import ctypes as C
+    cfg = S.CONFIGS["vit_base"]
+    B, per = 4096, 224 * 224 * 3
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_BF16, max_batch=B)
+    ctx.init_weights_seeded(0)
+    din = vithip.DeviceBuffer(B * per * 4)
+    dout = vithip.DeviceBuffer(B * cfg["classes"] * 4)
+    ctx.fill_input_seeded(1, B, din.ptr)
+    ctx.forward_device(din.ptr, B, dout.ptr)
+    full = dout.to_numpy(np.float32, (B, cfg["classes"]))
+    assert np.isfinite(full).all()
+    for lo, hi in ((0, 2), (2047, 2050), (4093, 4096)):
+        imgs = np.empty((hi - lo, 224, 224, 3), np.float32)
+        rc = vithip.lib().vh_memcpy_d2h(0, imgs.ctypes.data, C.c_void_p(din.ptr + lo * per * 4), imgs.nbytes)
+        assert rc == 0
+        assert np.array_equal(ctx.forward(imgs), full[lo:hi]), (lo, hi)
+    ctx.close()
+
+
 def test_concurrent_parts_give_bit_identical_logits():
     # vh_set_streams(n): the batch runs as n contiguous parts on n streams; images are independent, so every n
     # (and uneven splits: 5 images in 2, 3, 4 parts) must reproduce the single-stream logits bit for bit
