@@ -226,11 +226,34 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
             }
         }
     } else {
-        // fp32 out: rows of 64 floats = 256 B = 16 chunks, chunk ^ (r & 15); SMI/2 row blocks per pass
-        constexpr int FMI = SMI / 2;
+        // fp32 out: rows of 64 floats = 256 B = 16 chunks, chunk ^ (r & 15); SMI/2 row blocks per pass.
+        // The residual values of pass h+1 are loaded BEFORE pass h is staged, added and stored: written as
+        // "load, add, store" per line the loads could not move above the previous line's store (same array), so a
+        // tile's epilogue was a chain of 32 dependent HBM round trips -- latency-bound at a third of the HBM rate.
+        constexpr int FMI = SMI / 2, NP = MI / FMI, NL = FMI * 4;
+        constexpr bool RESID = EPI == VH_EPI_BIAS_RESID || EPI == VH_EPI_RESID_LN;
         const int rr = lane >> 4, pc = lane & 15;
+        f32x4 xv[2][RESID ? NL : 1];
+        auto line = [&](int h, int i, int& m, int& n) {
+            const int r = i * 4 + rr;
+            n = n_w + ((pc ^ (r & 15)) << 2);
+            m = m_w + h * FMI * 16 + r;
+            return (f32x4*)((float*)e.out + (int64_t)m * N + n);
+        };
+        auto load_pass = [&](int h, f32x4 (&x)[RESID ? NL : 1]) {
+            if constexpr (RESID) {
 #pragma unroll
-        for (int h = 0; h < MI / FMI; ++h) {
+                for (int i = 0; i < NL; ++i) {
+                    int m, n;
+                    const f32x4* p = line(h, i, m, n);
+                    x[i] = m < M ? *p : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        load_pass(0, xv[0]);
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            if (h + 1 < NP) load_pass(h + 1, xv[(h + 1) & 1]);
 #pragma unroll
             for (int mi = 0; mi < FMI; ++mi) {
                 const int r = mi * 16 + frow;
@@ -239,16 +262,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                     *(f32x4*)(sw + r * 256 + (((ni * 4 + fq) ^ (r & 15)) << 4)) = acc[h * FMI + mi][ni] + bv[ni];
             }
 #pragma unroll
-            for (int i = 0; i < FMI * 4; ++i) {
+            for (int i = 0; i < NL; ++i) {
                 const int r = i * 4 + rr;
                 f32x4 v = *(const f32x4*)(sw + r * 256 + (pc << 4));
-                const int n = n_w + ((pc ^ (r & 15)) << 2);
-                const int m = m_w + h * FMI * 16 + r;
+                int m, n;
+                f32x4* p = line(h, i, m, n);
                 const bool ok = m < M;
-                f32x4* p = (f32x4*)((float*)e.out + (int64_t)m * N + n);
-                if constexpr (EPI == VH_EPI_BIAS_RESID || EPI == VH_EPI_RESID_LN) {
-                    if (ok) v = v + *p;
-                }
+                if constexpr (RESID) v = v + xv[h & 1][i];
                 if (ok) *p = v;
                 if constexpr (EPI == VH_EPI_RESID_LN) {
                     // producer side of the folded LayerNorm: 16-bit copy + (sum, sumsq) of these 64 columns.

@@ -309,7 +309,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         if constexpr (F8 && EPI == VH_EPI_BIAS_GELU)
             gemm_epilogue8<EPI, MI, NI, VH_PP_SMI>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);
         else
-            gemm_epilogue<T, EPI, MI, NI, VH_PP_SMI, false>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);
+            gemm_epilogue<T, EPI, MI, NI, (epi_is_16bit(EPI) ? VH_PP_SMI : 4), false>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);   // fp32 forms: 32 rows per pass
         if (!has_next) break;
         if (nk > 1) {
             pp_barrier();  // every wave is done with its staging slice of stage 1
