@@ -196,6 +196,17 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
     if constexpr (epi_is_16bit(EPI)) {
         // rows of 64 x 16-bit = 128 B = 8 chunks of 16 B; chunk c of row r lives at chunk c ^ (r & 7)
         const int rr = lane >> 3, pc = lane & 7;
+        // LNFOLD: the (mean, rstd) pairs of the lane's MI rows are loaded up front -- read inside the loop they sit behind
+        // the previous pass's stores (possible alias), one exposed global-load latency per pass
+        float2 lnst[epi_is_lnfold(EPI) ? MI : 1];
+        if constexpr (epi_is_lnfold(EPI)) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int m = m_w + mi * 16 + frow;
+                m = m < M ? m : M - 1;
+                lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
+            }
+        }
 #pragma unroll
         for (int h = 0; h < MI / SMI; ++h) {
 #pragma unroll
@@ -203,9 +214,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 const int r = mi * 16 + frow;
                 float rstd = 0.f, mr = 0.f;
                 if constexpr (epi_is_lnfold(EPI)) {
-                    int m = m_w + h * SMI * 16 + r;
-                    m = m < M ? m : M - 1;
-                    const float2 st = *(const float2*)(e.stats + 2 * (int64_t)m);
+                    const float2 st = lnst[h * SMI + mi];
                     rstd = st.y;
                     mr = st.x * st.y;
                 }
