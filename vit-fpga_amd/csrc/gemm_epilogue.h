@@ -151,6 +151,18 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
             rstd = st.y;
             mr = st.x * st.y;
         }
+        // what the row ADDS (residual / position embedding) is loaded for all NI column blocks before the first store of
+        // the row: a load placed after a store to the same array cannot be moved above it
+        f32x4 addv[NI];
+        if constexpr (EPI == VH_EPI_BIAS_RESID || EPI == VH_EPI_PATCH) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = n0 + ni * 16;
+                const bool ok = !GUARD || n < N;
+                if constexpr (EPI == VH_EPI_BIAS_RESID) addv[ni] = ok ? *(const f32x4*)((const float*)e.out + orow * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                else addv[ni] = ok ? *(const f32x4*)(posrow + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n = n0 + ni * 16;
@@ -161,9 +173,8 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
             } else {
                 const f32x4 v = acc[mi][ni] + bv[ni];
                 f32x4* p = (f32x4*)((float*)e.out + orow * N + n);
-                if constexpr (EPI == VH_EPI_BIAS_RESID) *p = *p + v;
-                else if constexpr (EPI == VH_EPI_BIAS_F32) *p = v;
-                else *p = v + *(const f32x4*)(posrow + n);  // VH_EPI_PATCH
+                if constexpr (EPI == VH_EPI_BIAS_F32) *p = v;
+                else *p = v + addv[ni];  // VH_EPI_BIAS_RESID, VH_EPI_PATCH
             }
         }
     }
