@@ -149,7 +149,7 @@ def main():
         T = S.tokens(cfg)
         fc1_flops = 2.0 * (B / streams) * T * cfg["mlp_dim"] * cfg["dim"]  # every launch handles one part of the batch
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_l_fc1_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_o_fc1_traffic.json")
         if args.config == "vit_base" and B == 512 and streams == 1 and args.dtype == "bf16" and os.path.exists(tpath):
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]  # PMC passes of this command, see that file
         achieved = fc1_flops / (fc1_avg_ms * 1e-3) / 1e12 if fc1_avg_ms > 0 else 0.0
