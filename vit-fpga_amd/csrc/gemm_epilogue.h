@@ -188,7 +188,9 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
 // segments, 16 B per lane.  Write -> read-back is wave-private (no barrier).  `sw` = this wave's slice,
 // m_w / n_w = first row / column of the wave's sub-tile; rows >= M are skipped (ragged last M-tile).
 // SMI = 16-row blocks staged per pass for 16-bit output (slice = SMI * 2 KiB per wave); fp32 stages SMI/2.
-template <typename T, int EPI, int MI, int NI, int SMI = MI>
+// MFULL: every row of the wave's sub-tile is inside M (all but the last row tile of a GEMM): the 16-bit store loop then
+// carries no per-row predicate, so the read-backs of a pass are issued together instead of one per predicated block.
+template <typename T, int EPI, int MI, int NI, int SMI = MI, bool MFULL = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w,
                                                      int lane, char* sw) {
     static_assert(NI == 4, "staged epilogue assumes a 64-column wave tile");
@@ -242,7 +244,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 const u32x4 v = *(const u32x4*)(sw + r * 128 + (pc << 4));
                 const int n = n_w + ((pc ^ (r & 7)) << 3);
                 const int m = m_w + h * SMI * 16 + r;
-                if (m < M) __builtin_nontemporal_store(v, (u32x4*)((elem*)e.out + (int64_t)m * N + n));
+                if (MFULL || m < M) __builtin_nontemporal_store(v, (u32x4*)((elem*)e.out + (int64_t)m * N + n));
             }
         }
     } else {
@@ -313,7 +315,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const 
     if constexpr (EPI != VH_EPI_PATCH) {
         if (EPI == VH_EPI_RESID_LN || n_full) {
             if constexpr (BARRIER) __syncthreads();
-            gemm_epilogue_staged<T, EPI, MI, NI, SMI>(acc, e, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
+            if (m_full && epi_is_16bit(EPI)) gemm_epilogue_staged<T, EPI, MI, NI, SMI, true>(acc, e, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
+            else gemm_epilogue_staged<T, EPI, MI, NI, SMI, false>(acc, e, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
             return;
         }
     }
