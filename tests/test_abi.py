@@ -43,6 +43,16 @@ def test_header_is_plain_c_and_the_c_example_builds(tmp_path):
     assert subprocess.call([str(tmp_path / "probe")]) == 0
 
 
+def test_tools_and_entry_points_compile():
+    # the measurement scripts are part of the evidence trail (profiles/README.md names them): keep them importable
+    import py_compile
+    for rel in ("bench.py", "__graft_entry__.py", "tools/soak.py", "tools/parity_stats.py", "tools/pmc_summary.py",
+                "tools/gemm_bench.py", "tools/tiles_exp.py", "tools/fold_parity.py", "tests/golden/make_golden.py"):
+        py_compile.compile(os.path.join(ROOT, rel), doraise=True)
+    for rel in ("tools/power_probe.sh", "tools/ab_variant7.sh", "tools/ab_tail.sh", "tools/ab_supercol.sh", "tools/ab_attn.sh"):
+        subprocess.check_call(["bash", "-n", os.path.join(ROOT, rel)])
+
+
 def test_no_torch_or_oracle_dependency_in_the_product_library():
     out = subprocess.check_output(["readelf", "-d", vithip.LIB_PATH], text=True)
     needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
