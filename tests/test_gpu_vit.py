@@ -32,7 +32,7 @@ def rel(got, ref):
 
 
 @pytest.mark.parametrize("dt", [vithip.DTYPE_FP16, vithip.DTYPE_BF16])
-@pytest.mark.parametrize("name,batch", [("vit_micro", 5), ("vit_mini", 3), ("vit_tiny", 3), ("vit_base", 2)])
+@pytest.mark.parametrize("name,batch", [("vit_micro", 5), ("vit_mini", 3), ("vit_tiny", 3), ("vit_base", 2), ("vit_gray", 7)])
 def test_logits_match_oracle(dt, name, batch):
     cfg = S.CONFIGS[name]
     blob = S.make_blob(cfg, seed=0)

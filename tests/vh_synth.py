@@ -30,6 +30,9 @@ CONFIGS = {
                       layers=2, classes=40),
     "vit_mini": dict(image_size=96, patch_size=16, channels=3, dim=192, heads=3, mlp_dim=384,
                      layers=3, classes=100),
+    # odd corners: one channel, 32-pixel patches, 4-row patch grid, class count not a tile multiple
+    "vit_gray": dict(image_size=128, patch_size=32, channels=1, dim=128, heads=2, mlp_dim=320,
+                     layers=2, classes=12),
     # fp8 path (VH_DTYPE_FP8) needs dim and mlp_dim to be multiples of 128
     "vit_q8": dict(image_size=96, patch_size=16, channels=3, dim=256, heads=4, mlp_dim=640,
                    layers=3, classes=100),
