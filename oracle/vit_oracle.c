@@ -207,7 +207,12 @@ void oracle_layernorm(const float* x, int64_t rows, int dim, const float* gamma,
     }
 }
 
-void oracle_attention(const float* qkv, int batch, int tokens, int heads, int dh, float* out) {
+static void round16_buf(float* x, int64_t n, int dtype);
+static inline float round16_1(float f, int dtype);
+
+/* p_round: 0 = fp32 probabilities; 1 / 2 = the un-normalised exp(s - max) rounded to bf16 / fp16 before the P V
+ * product while the denominator keeps the unrounded values (the device's data flow, kernels_attn.hip) */
+static void attention_impl(const float* qkv, int batch, int tokens, int heads, int dh, float* out, int p_round) {
     const int D = heads * dh;
     const int64_t ld = 3 * (int64_t)D;
     const float scale = 1.0f / sqrtf((float)dh);
@@ -228,6 +233,7 @@ void oracle_attention(const float* qkv, int batch, int tokens, int heads, int dh
                     }
                     float den = 0.f;
                     for (int j = 0; j < tokens; ++j) { sc[j] = expf(sc[j] - mx); den += sc[j]; }
+                    if (p_round) for (int j = 0; j < tokens; ++j) sc[j] = round16_1(sc[j], p_round - 1);
                     const float inv = 1.0f / den;
                     float* o = out + ((int64_t)b * tokens + i) * D + h * dh;
                     for (int d = 0; d < dh; ++d) o[d] = 0.f;
@@ -241,6 +247,10 @@ void oracle_attention(const float* qkv, int batch, int tokens, int heads, int dh
         }
         free(sc);
     }
+}
+
+void oracle_attention(const float* qkv, int batch, int tokens, int heads, int dh, float* out) {
+    attention_impl(qkv, batch, tokens, heads, dh, out, 0);
 }
 
 void oracle_im2col(const float* in, int batch, int image, int patch, int channels, float* out) {
@@ -273,6 +283,14 @@ void oracle_round_bf16(float* x, int64_t n) {
 void oracle_round_fp16(float* x, int64_t n) {
     for (int64_t i = 0; i < n; ++i)
         x[i] = _cvtsh_ss(_cvtss_sh(x[i], _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+}
+
+static inline float round16_1(float f, int dtype) {
+    return dtype == 0 ? round_bf16_1(f) : _cvtsh_ss(_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+}
+static void round16_buf(float* x, int64_t n, int dtype) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) x[i] = round16_1(x[i], dtype);
 }
 
 /* ------------------------------------------------------------------------------------- */
@@ -339,8 +357,17 @@ static void linear_scaled(const float* a, const float* wq, const float* scale, c
         for (int n = 0; n < N; ++n) out[m * N + n] = out[m * N + n] * scale[n] + bias[n];
 }
 
+/* emul16: 0 = plain fp32; else 1 + dtype (1 = bf16, 2 = fp16) with `mask` choosing WHICH tensors are rounded to that
+ * 16-bit type on their way into a matrix product, i.e. where the device (vit-fpga_amd/csrc) holds an MFMA operand:
+ *   1 weights   2 LayerNorm output   4 q|k|v   8 softmax probabilities   16 attention output   32 GELU output
+ *   64 patch matrix   128 final-LN'd CLS rows   256 = LayerNorm FOLDED into q|k|v and fc1 (vithip_api.hip prepare_weights:
+ *   operand = the rounded RAW residual, weights = round(gamma o W), out = rstd (acc - mean c) + d) instead of bit 2.
+ * Everything else (accumulation, residual stream, statistics) stays fp32, as on the device.  Used to ATTRIBUTE the
+ * device's distance from the fp32 forward to its rounding points (tools/parity_attribution.py). */
 static int vit_forward_impl(const oracle_vit_config* c, const void* blob, const float* in,
-                       int batch, float* logits, float* hidden, int n_layers_run, int threads, int fp8) {
+                       int batch, float* logits, float* hidden, int n_layers_run, int threads, int fp8, int emul16, int mask) {
+    const int edt = emul16 - 1;
+#define EM(bit) (emul16 && (mask & (bit)))
     blob_header h;
     memcpy(&h, blob, sizeof h);
     if (memcmp(h.magic, "VHBLOB1", 8) != 0) return 1;
@@ -378,6 +405,15 @@ static int vit_forward_impl(const oracle_vit_config* c, const void* blob, const 
     float* wqkv = (float*)malloc(sizeof(float) * 3 * (size_t)D * D);
     float* bqkv = (float*)malloc(sizeof(float) * 3 * (size_t)D);
     if (!x || !y || !qkv || !att || !hid || !col || !pw || !wqkv || !bqkv) return 3;
+    float *wtmp = NULL, *cfold = NULL, *dfold = NULL, *stat = NULL;
+    if (emul16) {
+        const size_t big = (size_t)(Mh > 3 * D ? Mh : 3 * D) * D;
+        wtmp = (float*)malloc(sizeof(float) * (big > (size_t)C * D ? big : (size_t)C * D));
+        cfold = (float*)malloc(sizeof(float) * (size_t)(Mh > 3 * D ? Mh : 3 * D));
+        dfold = (float*)malloc(sizeof(float) * (size_t)(Mh > 3 * D ? Mh : 3 * D));
+        stat = (float*)malloc(sizeof(float) * rows * 2);
+        if (!wtmp || !cfold || !dfold || !stat) return 3;
+    }
     /* fp8 emulation: decoded e4m3 weights (largest matrix: mlp x dim) and their per-row scales */
     float *wq8 = NULL, *wsc = NULL;
     if (fp8) {
@@ -395,6 +431,8 @@ static int vit_forward_impl(const oracle_vit_config* c, const void* blob, const 
                     pw[(size_t)d * KP + (ky * P + kx) * CH + ch] =
                         patch_w[(((size_t)d * CH + ch) * P + ky) * P + kx];
     oracle_im2col(in, batch, c->image_size, P, CH, col);
+    if (EM(64)) round16_buf(col, (int64_t)batch * NP * KP, edt);
+    if (EM(1)) round16_buf(pw, (int64_t)D * KP, edt);
     oracle_linear(col, pw, patch_b, att /* scratch [batch*NP, D] */, (int64_t)batch * NP, D, KP);
     for (int b = 0; b < batch; ++b) {
         float* xb = x + (int64_t)b * T * D;
@@ -456,6 +494,58 @@ static int vit_forward_impl(const oracle_vit_config* c, const void* blob, const 
             for (int64_t i = 0; i < rows * D; ++i) x[i] += y[i];
             continue;
         }
+        if (emul16) {
+            /* a LayerNorm + linear pair: plain (LN in fp32, its output and the weights rounded on request) or folded */
+#define LN_LINEAR(lnw, lnb, W, B, OUT, NOUT)                                                                         \
+            if (EM(256)) {                                                                                           \
+                /* folded: W' = round(gamma o W), c = row sums of W', d = W beta + b; operand = round(x) */          \
+                for (int n = 0; n < (NOUT); ++n) {                                                                   \
+                    double cs = 0.0, ds = 0.0;                                                                       \
+                    for (int k = 0; k < D; ++k) {                                                                    \
+                        const float wg = round16_1((W)[(size_t)n * D + k] * (lnw)[k], edt);                          \
+                        wtmp[(size_t)n * D + k] = wg; cs += wg; ds += (double)(W)[(size_t)n * D + k] * (lnb)[k];     \
+                    }                                                                                                \
+                    cfold[n] = (float)cs; dfold[n] = (float)ds + (B)[n];                                             \
+                }                                                                                                    \
+                _Pragma("omp parallel for schedule(static)")                                                         \
+                for (int64_t r = 0; r < rows; ++r) {                                                                 \
+                    const float* xr = x + r * D; double s1 = 0.0, s2 = 0.0;                                          \
+                    for (int k = 0; k < D; ++k) { s1 += xr[k]; s2 += (double)xr[k] * xr[k]; y[r * D + k] = round16_1(xr[k], edt); } \
+                    const double mean = s1 / D; double var = s2 / D - mean * mean; if (var < 0) var = 0;             \
+                    stat[2 * r] = (float)mean; stat[2 * r + 1] = (float)(1.0 / sqrt(var + (double)c->ln_eps));       \
+                }                                                                                                    \
+                oracle_linear(y, wtmp, NULL, OUT, rows, NOUT, D);                                                    \
+                _Pragma("omp parallel for schedule(static)")                                                         \
+                for (int64_t r = 0; r < rows; ++r)                                                                   \
+                    for (int n = 0; n < (NOUT); ++n)                                                                 \
+                        (OUT)[r * (NOUT) + n] = stat[2 * r + 1] * ((OUT)[r * (NOUT) + n] - stat[2 * r] * cfold[n]) + dfold[n]; \
+            } else {                                                                                                 \
+                oracle_layernorm(x, rows, D, lnw, lnb, c->ln_eps, y);                                                \
+                if (EM(2)) round16_buf(y, rows * D, edt);                                                            \
+                memcpy(wtmp, W, sizeof(float) * (size_t)(NOUT) * D);                                                 \
+                if (EM(1)) round16_buf(wtmp, (int64_t)(NOUT) * D, edt);                                              \
+                oracle_linear(y, wtmp, B, OUT, rows, NOUT, D);                                                       \
+            }
+            LN_LINEAR(ln1w, ln1b, wqkv, bqkv, qkv, 3 * D)
+            if (EM(4)) round16_buf(qkv, rows * 3 * D, edt);
+            attention_impl(qkv, batch, T, H, dh, att, EM(8) ? 1 + edt : 0);
+            if (EM(16)) round16_buf(att, rows * D, edt);
+            memcpy(wtmp, ow, sizeof(float) * (size_t)D * D);
+            if (EM(1)) round16_buf(wtmp, (int64_t)D * D, edt);
+            oracle_linear(att, wtmp, ob, y, rows, D, D);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < rows * D; ++i) x[i] += y[i];
+            LN_LINEAR(ln2w, ln2b, f1w, f1b, hid, Mh)
+            oracle_gelu(hid, rows * Mh);
+            if (EM(32)) round16_buf(hid, rows * Mh, edt);
+            memcpy(wtmp, f2w, sizeof(float) * (size_t)D * Mh);
+            if (EM(1)) round16_buf(wtmp, (int64_t)D * Mh, edt);
+            oracle_linear(hid, wtmp, f2b, y, rows, D, Mh);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < rows * D; ++i) x[i] += y[i];
+#undef LN_LINEAR
+            continue;
+        }
         oracle_layernorm(x, rows, D, ln1w, ln1b, c->ln_eps, y);
         oracle_linear(y, wqkv, bqkv, qkv, rows, 3 * D, D);
         oracle_attention(qkv, batch, T, H, dh, att);
@@ -474,10 +564,17 @@ static int vit_forward_impl(const oracle_vit_config* c, const void* blob, const 
     /* final LN on the CLS rows only, then the head */
     for (int b = 0; b < batch; ++b)
         oracle_layernorm(x + (int64_t)b * T * D, 1, D, fin, fin + D, c->ln_eps, y + (int64_t)b * D);
+    if (EM(128)) round16_buf(y, (int64_t)batch * D, edt);
+    if (EM(1)) {
+        memcpy(wtmp, fin + 2 * D, sizeof(float) * (size_t)C * D);
+        round16_buf(wtmp, (int64_t)C * D, edt);
+        oracle_linear(y, wtmp, fin + 2 * D + (size_t)C * D, logits, batch, C, D);
+    } else
     oracle_linear(y, fin + 2 * D, fin + 2 * D + (size_t)C * D, logits, batch, C, D);
 
     free(x); free(y); free(qkv); free(att); free(hid); free(col); free(pw); free(wqkv); free(bqkv);
-    free(wq8); free(wsc);
+    free(wq8); free(wsc); free(wtmp); free(cfold); free(dfold); free(stat);
+#undef EM
     return 0;
 }
 
@@ -510,9 +607,14 @@ void oracle_filter3x3(const uint8_t* in, uint8_t* out, int h, int w, int kind) {
 
 int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float* in,
                        int batch, float* logits, float* hidden, int n_layers_run, int threads) {
-    return vit_forward_impl(c, blob, in, batch, logits, hidden, n_layers_run, threads, 0);
+    return vit_forward_impl(c, blob, in, batch, logits, hidden, n_layers_run, threads, 0, 0, 0);
+}
+int oracle_vit_forward_emul16(const oracle_vit_config* c, const void* blob, const float* in, int batch, float* logits,
+                              int dtype, int mask, int threads) {
+    if (dtype != 0 && dtype != 1) return 4;
+    return vit_forward_impl(c, blob, in, batch, logits, NULL, -1, threads, 0, 1 + dtype, mask);
 }
 int oracle_vit_forward_fp8(const oracle_vit_config* c, const void* blob, const float* in,
                            int batch, float* logits, float* hidden, int n_layers_run, int threads) {
-    return vit_forward_impl(c, blob, in, batch, logits, hidden, n_layers_run, threads, 1);
+    return vit_forward_impl(c, blob, in, batch, logits, hidden, n_layers_run, threads, 1, 0, 0);
 }

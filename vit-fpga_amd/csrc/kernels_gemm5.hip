@@ -55,6 +55,36 @@
 
 namespace vh {
 
+// ---- DIAGNOSTIC BUILD ONLY (-DVH_DIAG_STAMPS -> libvithip_diag.so, tools/gemm_anatomy.py) ---------------------------
+// Wave 0 of every workgroup stamps s_memrealtime (100 MHz, chip-wide) at: kernel entry, first K-tile visible, end of
+// the main loop, epilogue issued, stores drained; s_memtime (shader clock) around the main loop (in-kernel clock =
+// d(s_memtime) / d(s_memrealtime) x 100 MHz, MI355X_MICROARCH.md "DVFS give-back" item 6); and the hardware id of its
+// CU.  The stamps go to a ring buffer of their own that nothing else reads; no output depends on them.  In the
+// product build (no VH_DIAG_STAMPS) none of this exists: no parameter, no instruction.
+#ifdef VH_DIAG_STAMPS
+#define VH_STAMP_PARAM , unsigned long long* __restrict__ stamps
+__device__ __forceinline__ unsigned long long diag_rt() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long diag_ct() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long diag_hwid() {
+    unsigned int hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return ((unsigned long long)xcc << 32) | hw;
+}
+#define VH_STAMP(i, expr) do { __builtin_amdgcn_sched_barrier(0); st_[i] = (expr); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VH_STAMP_PARAM
+#define VH_STAMP(i, expr) do { } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void pp_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -74,8 +104,13 @@ __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                   const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
-                  void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn) {
+                  void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn VH_STAMP_PARAM) {
     using vec8 = typename T::vec8;
+#ifdef VH_DIAG_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool first_tile_ = true;
+#endif
+    VH_STAMP(0, diag_rt());
     constexpr int BM = 256, BN = 256;
     constexpr int KT_BYTES = 128;                  // one K-tile row: 64 16-bit or 128 8-bit elements
     constexpr int STAGE_BYTES = 65536, W_OFF = 32768;
@@ -175,6 +210,9 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         else pp_wait_vmcnt<0>();
         pp_barrier();                 // K-tile 0 visible
         if (grp == 1) pp_barrier();   // G1 runs one phase behind
+#ifdef VH_DIAG_STAMPS
+        if (first_tile_) { VH_STAMP(1, diag_rt()); VH_STAMP(5, diag_ct()); }
+#endif
 
         if constexpr (F8) {
             i32x8 wf[NI], xf[MI / 2];
@@ -284,6 +322,9 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         }
         }
         if (grp == 0) pp_barrier();  // G0 waits for G1's last phase: every LDS read of this tile is complete
+#ifdef VH_DIAG_STAMPS
+        if (first_tile_) { VH_STAMP(6, diag_ct()); VH_STAMP(2, diag_rt()); }
+#endif
 
         // ---- tile boundary --------------------------------------------------------------------------------------
         const int m_w = tile_m * BM + grp * 128, n_w = tile_n * BN + wn * 64;
@@ -310,6 +351,19 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             gemm_epilogue8<EPI, MI, NI, VH_PP_SMI>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);
         else
             gemm_epilogue<T, EPI, MI, NI, (epi_is_16bit(EPI) ? VH_PP_SMI : 4), false>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);   // fp32 forms: 32 rows per pass
+#ifdef VH_DIAG_STAMPS
+        if (first_tile_) {
+            VH_STAMP(3, diag_rt());
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            VH_STAMP(4, diag_rt());
+            st_[7] = diag_hwid();
+            if (stamps && threadIdx.x == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) stamps[(size_t)blockIdx.x * 8 + i] = st_[i];
+            }
+            first_tile_ = false;
+        }
+#endif
         if (!has_next) break;
         if (nk > 1) {
             pp_barrier();  // every wave is done with its staging slice of stage 1
@@ -333,6 +387,25 @@ static int gemm_super_columns(int tiles_n) {
     return 4;
 }
 
+#ifdef VH_DIAG_STAMPS
+// ring of the most recent launches' stamps (host bookkeeping; one device buffer of slots x max_wgs x 8 words)
+struct DiagRec { int64_t M; int N, K, epi, f8, grid, variant; };
+static unsigned long long* g_diag_buf = nullptr;
+static int g_diag_slots = 0, g_diag_max_wgs = 0;
+static long long g_diag_count = 0;
+static DiagRec g_diag_rec[1024];
+static unsigned long long* diag_next(const GemmArgs& g, int epi, bool f8, int grid, int variant) {
+    if (!g_diag_buf || grid > g_diag_max_wgs) return nullptr;
+    const int slot = (int)(g_diag_count % g_diag_slots);
+    g_diag_rec[slot] = DiagRec{g.M, g.N, g.K, epi, f8 ? 1 : 0, grid, variant};
+    ++g_diag_count;
+    return g_diag_buf + (size_t)slot * g_diag_max_wgs * 8;
+}
+#define VH_STAMP_ARG(g, epi, f8, grid, variant) , diag_next(g, epi, f8, grid, variant)
+#else
+#define VH_STAMP_ARG(g, epi, f8, grid, variant)
+#endif
+
 // mode 0: one tile per workgroup (variant 5); 1: persistent (6); 2: one tile per workgroup, three A stages (7)
 template <typename T, int EPI, bool F8, bool PERSIST, int AST>
 static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int tiles_n, hipStream_t s) {
@@ -341,7 +414,8 @@ static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int ti
     static int lds_done[kMaxDevices] = {0};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
-                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n));
+                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n)
+                       VH_STAMP_ARG(g, EPI, F8, grid, PERSIST ? 6 : (AST == 3 ? 7 : 5)));
     return hipGetLastError();
 }
 
@@ -400,3 +474,29 @@ hipError_t launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
 }
 
 }  // namespace vh
+
+#ifdef VH_DIAG_STAMPS
+// exported by libvithip_diag.so only (not declared in include/vithip.h; bound by tools/gemm_anatomy.py)
+extern "C" int vh_diag_stamps_arm(int slots, int max_wgs) {
+    using namespace vh;
+    if (slots < 1 || slots > 1024 || max_wgs < 1) return 1;
+    if (g_diag_buf) { hipFree(g_diag_buf); g_diag_buf = nullptr; }
+    if (hipMalloc((void**)&g_diag_buf, (size_t)slots * max_wgs * 64) != hipSuccess) return 2;
+    if (hipMemset(g_diag_buf, 0, (size_t)slots * max_wgs * 64) != hipSuccess) return 2;
+    g_diag_slots = slots; g_diag_max_wgs = max_wgs; g_diag_count = 0;
+    return 0;
+}
+// age 0 = the most recent launch; copies grid x 8 words; meta = {M, N, K, epi, f8, grid, variant}
+extern "C" int vh_diag_stamps_read(int age, unsigned long long* host, int max_wgs, long long* meta) {
+    using namespace vh;
+    if (!g_diag_buf || age < 0 || age >= g_diag_slots || age >= g_diag_count) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    const int slot = (int)((g_diag_count - 1 - age) % g_diag_slots);
+    const DiagRec& r = g_diag_rec[slot];
+    if (r.grid > max_wgs) return 3;
+    if (hipMemcpy(host, g_diag_buf + (size_t)slot * g_diag_max_wgs * 8, (size_t)r.grid * 64, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    meta[0] = r.M; meta[1] = r.N; meta[2] = r.K; meta[3] = r.epi; meta[4] = r.f8; meta[5] = r.grid; meta[6] = r.variant;
+    return 0;
+}
+extern "C" long long vh_diag_stamps_count(void) { return vh::g_diag_count; }
+#endif
