@@ -124,6 +124,25 @@ def vit_forward(cfg, blob, images, n_layers=-1, threads=0, want_hidden=False, ln
     return (logits, hidden) if want_hidden else logits
 
 
+EMUL_BITS = {"weights": 1, "ln_out": 2, "qkv": 4, "probs": 8, "attn_out": 16, "gelu_out": 32, "patches": 64, "cls_rows": 128,
+             "ln_folded": 256}
+
+
+def vit_forward_emul16(cfg, blob, images, dtype, mask, threads=0, ln_eps=1e-6):
+    """fp32 forward with the device's 16-bit rounding points switched on by `mask` (oracle.h, EMUL_BITS);
+    dtype 0 = bf16, 1 = fp16."""
+    c = cfg_struct(cfg, ln_eps)
+    images = _f32(images)
+    batch = images.shape[0]
+    logits = np.empty((batch, cfg["classes"]), dtype=np.float32)
+    fn = lib().oracle_vit_forward_emul16
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rc = fn(C.byref(c), blob.ctypes.data, images.ctypes.data, batch, logits.ctypes.data, dtype, mask, threads)
+    assert rc == 0, rc
+    return logits
+
+
 def quant_e4m3(x):
     """decode(encode(x)): x rounded to the nearest e4m3 value, saturating at +-448."""
     x = _f32(x).copy()

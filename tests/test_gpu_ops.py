@@ -366,3 +366,37 @@ def test_gemm_resid_ln_epilogue(dt, variant):
     g64 = got.astype(np.float64).reshape(M, N // 64, 64)
     assert np.abs(p[:, :, 0].T - g64.sum(2)).max() <= 1e-4
     assert np.abs(p[:, :, 1].T - (g64 ** 2).sum(2)).max() <= 1e-4 * (g64 ** 2).sum(2).max()
+
+
+@pytest.mark.parametrize("dt", [vithip.DTYPE_BF16, vithip.DTYPE_FP16])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "lnfold_gelu"])
+def test_gemm_persistent_walks_several_tiles_per_workgroup(dt, epi):
+    """The persistent ping-pong form (variant 6, the default for 16-bit results): with more tiles than CUs a workgroup
+    runs 2-3 tiles back to back, prefetching the next tile's first K-tile from inside the epilogue.  Same arithmetic in
+    the same order as the one-tile-per-workgroup form (variant 5), so the results must be bit-identical to it; the
+    oracle pins both.  Ragged M, K = 3 K-tiles / 1 K-tile / 2 K-tiles."""
+    rng = np.random.default_rng(7)
+    for M, N, K in ((256 * 141 + 37, 1024, 192), (256 * 70 + 5, 2048, 64), (256 * 67, 1280, 128)):
+        a = (rng.random((M, K), dtype=np.float32) * 2 - 1)
+        w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+        b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+        a16, w16 = vithip.to16(a, dt), vithip.to16(w, dt)
+        A, W, Bv = dev(a16), dev(w16), dev(b)
+        outs = []
+        st = np.stack([rng.standard_normal(M) * 0.1, 1.0 + rng.random(M)], axis=1).astype(np.float32)
+        cvec = (rng.standard_normal(N) * 0.1).astype(np.float32)
+        for variant in (5, 6):
+            out = vithip.DeviceBuffer(M * N * 2)
+            if epi == "lnfold_gelu":
+                vithip.op_gemm_ex(A.ptr, W.ptr, Bv.ptr, out.ptr, M, N, K, vithip.EPI_LNFOLD_GELU, dt,
+                                  aux_ptr=dev(cvec).ptr, stats_ptr=dev(st).ptr, variant=variant)
+            else:
+                vithip.op_gemm(A.ptr, W.ptr, Bv.ptr, out.ptr, M, N, K,
+                               vithip.EPI_BIAS if epi == "bias" else vithip.EPI_BIAS_GELU, dt, variant=variant)
+            outs.append(out.to_numpy(np.uint16, (M, N)).copy())
+            out.free()
+        assert np.array_equal(outs[0], outs[1]), f"variant 6 differs from variant 5 at {(outs[0] != outs[1]).sum()} of {M * N} elements ({M}x{N}x{K})"
+        if epi == "bias":
+            ref = vithip.from16(a16, dt).astype(np.float64) @ vithip.from16(w16, dt).astype(np.float64).T + b
+            got = vithip.from16(outs[1], dt)
+            assert np.abs(got - ref).max() <= (2e-2 if dt == vithip.DTYPE_BF16 else 3e-3) * max(1.0, np.abs(ref).max())

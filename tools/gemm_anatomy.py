@@ -65,20 +65,34 @@ def main():
 
     groups = {}
     n = min(args.launches, int(L.vh_diag_stamps_count()))
-    buf = np.zeros((max_wgs, 8), dtype=np.uint64)
+    buf = np.zeros((max_wgs, 8, 8), dtype=np.uint64)   # [workgroup][wave][stamp]
     meta = (ctypes.c_longlong * 8)()
     for age in range(n):
         if L.vh_diag_stamps_read(age, buf.ctypes.data, max_wgs, meta):
             continue
         M, N, K, epi, f8, grid, variant = [int(meta[i]) for i in range(7)]
         groups.setdefault((M, N, K, epi, f8, variant), []).append(buf[:grid].copy())
+    waves = {}
 
     print(f"{'shape (M N K epilogue)':44s} {'launches':>8s} {'tiles':>6s} {'span us':>8s} | per tile, us: {'prologue':>8s} {'main':>7s} {'epi issue':>9s} {'drain':>6s} "
           f"{'gap':>6s} | {'clk GHz':>7s} {'MFMA busy% of main':>18s} {'main share%':>11s} {'PF':>6s}")
     for key, launches in sorted(groups.items(), key=lambda kv: -kv[0][1] * kv[0][2]):
         M, N, K, epi, f8, variant = key
         pro, mainl, epi_t, drain, gaps, clk, span = [], [], [], [], [], [], []
-        for st in launches:
+        wv = np.zeros((8, 4))
+        nwv = 0
+        for st8 in launches:
+            s8 = st8.astype(np.int64)
+            okw = (s8[:, :, 4] > 0).all(axis=1)
+            if okw.any():
+                # per wave, relative to wave 0's top-of-tile stamp: end of main loop, epilogue issued, iteration end
+                base = s8[okw, 0:1, 0]
+                wv[:, 0] += ((s8[okw, :, 1] - base).mean(axis=0)) / 100.0
+                wv[:, 1] += ((s8[okw, :, 2] - base).mean(axis=0)) / 100.0
+                wv[:, 2] += ((s8[okw, :, 3] - base).mean(axis=0)) / 100.0
+                wv[:, 3] += ((s8[okw, :, 4] - base).mean(axis=0)) / 100.0
+                nwv += 1
+            st = st8[:, 0, :]
             s = st.astype(np.int64)
             ok = s[:, 4] > 0
             s = s[ok]
@@ -114,6 +128,11 @@ def main():
         print(f"{M:7d} {N:5d} {K:5d} {EPI.get(epi, str(epi)):>16s}{' e4m3' if f8 else '':5s} v{variant} {len(launches):8d} {tiles:6d} {np.mean(span):8.1f} | "
               f"{'':13s} {np.mean(pro):8.2f} {m_us:7.2f} {np.mean(epi_t):9.2f} {np.mean(drain):6.2f} {np.mean(gaps) if gaps else float('nan'):6.2f} | "
               f"{c:7.3f} {busy:18.1f} {100.0 * m_us / tile_us:11.1f} {pf:6.3f}")
+        if nwv:
+            wv /= nwv
+            print("      per wave (us after wave 0's top-of-tile stamp): loop entered | main loop done | epilogue issued | iteration end")
+            for w in range(8):
+                print(f"        wave {w}: {wv[w, 0]:7.2f} {wv[w, 1]:7.2f} {wv[w, 2]:7.2f} {wv[w, 3]:7.2f}")
     ctx.close()
 
 

@@ -174,17 +174,23 @@ static hipError_t launch_epi(const GemmArgs& g, int variant, hipStream_t s) {
     }
 }
 
-// which ping-pong form large shapes take: 5 (two A stages), 6 (persistent) or 7 (three A stages); VH_GEMM_PP overrides
-int gemm_pp_variant() {
-    static int v = 0;
-    if (!v) {
+// which ping-pong form a large shape takes.  Default: the PERSISTENT form (6: one workgroup per CU walks the tiles and
+// DMA-prefetches the next tile's first K-tile under the current epilogue) for the epilogues with a 16-bit result (q|k|v,
+// fc1: no loads inside the epilogue once its leading bias / statistics loads are in), the one-tile-per-workgroup form (5)
+// for the fp32 read-modify-write epilogues (their residual loads run through the whole epilogue, and the persistent
+// instantiation of them does not fit the register file without spills inside the K loop).  VH_GEMM_PP = 5 / 6 / 7 forces
+// one form for every epilogue (A/B runs, tests).
+int gemm_pp_variant(int epilogue) {
+    static int v = -1;
+    if (v < 0) {
         const char* e = getenv("VH_GEMM_PP");
-        v = e ? atoi(e) : 5;
-        if (v < 5 || v > 7) v = 5;
+        v = e ? atoi(e) : 0;
+        if (v < 5 || v > 7) v = 0;
     }
-    return v;
+    if (v) return v;
+    return epi_is_16bit(epilogue) ? 6 : 5;
 }
-int gemm_pick_variant(int64_t M, int N) {
+int gemm_pick_variant(int64_t M, int N, int epilogue) {
     static int min_tiles = 0;
     if (!min_tiles) {
         const char* e = getenv("VH_PP_MIN_TILES");
@@ -192,7 +198,7 @@ int gemm_pick_variant(int64_t M, int N) {
         if (min_tiles < 1) min_tiles = 1;
     }
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-    return t256 >= min_tiles ? gemm_pp_variant() : 1;  // the 256x256 ping-pong kernel needs enough tiles for the 256 CUs
+    return t256 >= min_tiles ? gemm_pp_variant(epilogue) : 1;  // the 256x256 ping-pong kernel needs enough tiles for the 256 CUs
 }
 
 const char* gemm_check(const GemmArgs& g) {
@@ -213,7 +219,7 @@ const char* gemm_check(const GemmArgs& g) {
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (gemm_check(g)) return hipErrorInvalidValue;
-    const int variant = g.variant ? g.variant : gemm_pick_variant(g.M, g.N);
+    const int variant = g.variant ? g.variant : gemm_pick_variant(g.M, g.N, g.epilogue);
     if ((g.tile_count || g.tile_begin) && variant != 5 && variant != 7) return hipErrorInvalidValue;  // tile ranges: ping-pong forms only
     return g.dtype == VH_DTYPE_BF16 ? launch_epi<BF16>(g, variant, s) : launch_epi<FP16>(g, variant, s);
 }

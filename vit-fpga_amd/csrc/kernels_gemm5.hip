@@ -45,6 +45,7 @@
 // (same 512 matrix cycles per phase, same 64 fragment registers).  W carries one fp32 scale per output channel
 // (`aux`), applied to the accumulators before the epilogue; activations are unscaled (vh_common.h, E4M3).
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_epilogue.h"
 #include "vh_kernels.h"
@@ -99,18 +100,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {  // bijective on [0, 
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
 }
 
+__device__ __forceinline__ int nk_of(int64_t row_bytes) { return (int)(row_bytes / 128); }
+
 template <typename T, int EPI, bool PERSIST, bool F8 = false, int AST = 2>
 __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                   const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
-                  void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn VH_STAMP_PARAM) {
+                  void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn, int stagger VH_STAMP_PARAM) {
     using vec8 = typename T::vec8;
 #ifdef VH_DIAG_STAMPS
+    // the iteration whose stamps are kept: the workgroup's only tile, or the SECOND tile of a persistent workgroup
+    // (steady state: its K-tile 0 was prefetched under the previous tile's epilogue)
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool first_tile_ = true;
+    int it_ = 0;
+    constexpr int rec_it_ = PERSIST ? 1 : 0;
+#define first_tile_ (it_ == rec_it_)
 #endif
-    VH_STAMP(0, diag_rt());
     constexpr int BM = 256, BN = 256;
     constexpr int KT_BYTES = 128;                  // one K-tile row: 64 16-bit or 128 8-bit elements
     constexpr int STAGE_BYTES = 65536, W_OFF = 32768;
@@ -136,49 +142,59 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     const int grp = wave >> 2, wn = wave & 3;
 
     // ---- DMA: this wave moves 4 x 1 KiB of its group's A half and 4 x 1 KiB of its group's W half -------
+    // A source address = wave-uniform panel base (first row of the tile, 64-bit, scalar registers) + a per-lane
+    // 32-bit byte offset (row inside the tile x row_bytes + swizzled 16-B chunk): 8 address registers per wave
+    // instead of 16 (4 in the persistent form) and no 64-bit vector adds per DMA.
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
-    const char *gA[4], *gW[4];
+    const int rb = (int)row_bytes;
+    struct TileSrc { const char *a, *w; uint32_t oa[4], ow[4]; };
     int tile_m = 0, tile_n = 0;
-    auto setup_tile = [&](int tt) {
+    auto tile_coords = [&](int tt, int& tm, int& tn) {
         // Tile order.  sn == 0: n fastest over all tiles_n column tiles.  sn > 0: super-columns of sn column tiles, m
         // fastest-but-one inside each: the workgroups of an XCD then share sn W panels (which stay in its 4 MiB L2
         // from round to round) instead of all tiles_n (fc1: 12 panels = 4.7 MB, re-fetched from beyond L2 every round).
         if (sn > 0) {
             const int blk = tiles_m * sn, sc = tt / blk, r = tt - sc * blk;
             const int width = tiles_n - sc * sn < sn ? tiles_n - sc * sn : sn;
-            tile_m = r / width;
-            tile_n = sc * sn + (r - tile_m * width);
+            tm = r / width;
+            tn = sc * sn + (r - tm * width);
         } else {
-            tile_m = tt / tiles_n;
-            tile_n = tt - tile_m * tiles_n;
+            tm = tt / tiles_n;
+            tn = tt - tm * tiles_n;
         }
+    };
+    auto base_a = [&](int tm) { return A + (int64_t)tm * BM * row_bytes; };
+    auto base_w = [&](int tn) { return W + (int64_t)tn * BN * row_bytes; };
+    TileSrc cur;
+    auto setup_tile = [&](int tt) {
+        tile_coords(tt, tile_m, tile_n);
+        cur.a = base_a(tile_m);
+        cur.w = base_w(tile_n);
+        // last valid row inside the tile (rows beyond it replicate it).  Persistent form: full tiles only, so the per-lane
+        // offsets are the same for A and W and for every tile -- only the scalar bases change from tile to tile.
+        const int ma = PERSIST ? 255 : M - 1 - tile_m * BM, mw = PERSIST ? 255 : N - 1 - tile_n * BN;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = grp * 128 + (i * 4 + wn) * 8 + lr;
-            int ra = tile_m * BM + r, rw = tile_n * BN + r;
-            ra = ra < M ? ra : M - 1;
-            rw = rw < N ? rw : N - 1;
-            gA[i] = A + ra * row_bytes + lc * 16;
-            gW[i] = W + rw * row_bytes + lc * 16;
+            cur.oa[i] = (uint32_t)((r < ma ? r : ma) * rb + lc * 16);
+            if constexpr (!PERSIST) cur.ow[i] = (uint32_t)((r < mw ? r : mw) * rb + lc * 16);
         }
     };
     const int dma_off = grp * 16384 + wn * 1024;  // + i * 4096
-    auto a_off = [&](int kt, int kt3) { return AST == 2 ? (kt & 1) * STAGE_BYTES : 2 * W_OFF + kt3 * 32768; };
-    auto w_off = [&](int kt) { return AST == 2 ? (kt & 1) * STAGE_BYTES + W_OFF : (kt & 1) * W_OFF; };
-    auto issue_a = [&](int kt, int kt3 = 0) {
-        char* dst = smem + a_off(kt, kt3) + dma_off;
+    // LDS stage of K-tile kt of the current tile.  One tile per workgroup: kt & 1.  Persistent form: the K-tiles of
+    // consecutive tiles form ONE stream through the two stages, so a tile's K-tile 0 sits in stage `par` (the parity of
+    // the K-tiles that went before).
+    int par = 0;
+    auto a_off = [&](int kt, int kt3) { return AST == 2 ? ((par + kt) & 1) * STAGE_BYTES : 2 * W_OFF + kt3 * 32768; };
+    auto w_off = [&](int kt) { return AST == 2 ? ((par + kt) & 1) * STAGE_BYTES + W_OFF : (kt & 1) * W_OFF; };
+    auto dma4 = [&](const char* base, const uint32_t (&off)[4], char* dst) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gA[i] + kt * KT_BYTES),
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + off[i]),
                                              (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
     };
-    auto issue_w = [&](int kt) {
-        char* dst = smem + w_off(kt) + dma_off;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gW[i] + kt * KT_BYTES),
-                                             (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
-    };
+    auto issue_a = [&](int kt, int kt3 = 0) { dma4(cur.a + (int64_t)kt * KT_BYTES, cur.oa, smem + a_off(kt, kt3) + dma_off); };
+    auto issue_w = [&](int kt) { dma4(cur.w + (int64_t)kt * KT_BYTES, PERSIST ? cur.oa : cur.ow, smem + w_off(kt) + dma_off); };
 
     // ---- fragment addresses ----------------------------------------------------------------------------------
     const int frow = lane & 15, fq = lane >> 4;
@@ -190,6 +206,18 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 
     const int nk = (int)(row_bytes / KT_BYTES);
 
+    // Persistent form, optional: workgroups start `stagger` phases apart over one tile period.  Identical workgroups
+    // started together stay in lockstep (nothing re-shuffles them as the dispatcher does between one-tile workgroups),
+    // so all 256 epilogues -- 32 MB of stores -- would hit HBM in the same few microseconds of every tile period.
+    if constexpr (PERSIST) {
+        if (stagger > 1) {
+            const unsigned phase = (blockIdx.x >> 3) % (unsigned)stagger;
+            const unsigned long long ticks = (unsigned long long)phase * (unsigned)(nk_of(row_bytes) * 150 + 500) / (unsigned)stagger;   // 100 MHz ticks; ~1.5 us per K-tile + 5 us epilogue
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+
     // ---- prologue of the first tile: K-tiles 0 and 1 ------------------------------------------------------------
     setup_tile(t);
     issue_w(0);
@@ -198,21 +226,71 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         issue_w(1);
         issue_a(1, 1);
     }
+    if (nk > 1) pp_wait_vmcnt<8>();  // K-tile 0 landed, K-tile 1 may fly
+    else pp_wait_vmcnt<0>();
+    pp_barrier();                    // K-tile 0 visible
 
+    // Persistent form (nk >= 2, full tiles only: the launcher sees to both): the DMA stream does not stop at a tile
+    // boundary.  The slots of the schedule that would fetch K-tiles nk and nk + 1 of the current tile fetch K-tiles 0 and
+    // 1 of the NEXT tile instead -- A(next, 0) in L0(nk-1), W(next, 0) in L1(nk-2), W(next, 1) in L1(nk-1), A(next, 1) in
+    // L0 of the next tile's K-tile 0 -- with the usual counted waits, so a tile's first operands are in LDS when its loop
+    // starts: no per-tile prologue, no launch gap, no burst of DMAs.  The epilogue stages through an LDS region of its own
+    // behind the two stages (160 KiB in this form), and its loads and stores simply join the in-order queue: its leading
+    // loads wait for W(next, 1), issued one phase earlier; its stores are retired by the next tile's first counted wait.
+    bool first = true;   // first tile of this workgroup: A(1) came from the prologue above
     while (true) {
+#ifdef VH_DIAG_STAMPS
+        if (first_tile_) VH_STAMP(0, diag_rt());
+#endif
         f32x4 acc[MI][NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        if (nk > 1) pp_wait_vmcnt<8>();  // K-tile 0 landed (and any earlier stores), K-tile 1 may fly
-        else pp_wait_vmcnt<0>();
-        pp_barrier();                 // K-tile 0 visible
+        const int t_next = t + stride;
+        const bool has_next = PERSIST && t_next < ntiles;
+        int tm_n = 0, tn_n = 0;
+        if (has_next) tile_coords(t_next, tm_n, tn_n);
+
         if (grp == 1) pp_barrier();   // G1 runs one phase behind
 #ifdef VH_DIAG_STAMPS
         if (first_tile_) { VH_STAMP(1, diag_rt()); VH_STAMP(5, diag_ct()); }
 #endif
+
+        // the DMA slots of one K-tile (AST == 2 unless noted)
+        auto l0_issue = [&](int kt, int k3) {
+            if (AST == 3) { if (kt + 2 < nk) issue_a(kt + 2, k3 == 0 ? 2 : k3 - 1); }
+            else if (kt + 1 < nk) { if (kt >= 1 || (PERSIST && !first)) issue_a(kt + 1); }
+            else if (has_next) {   // kt == nk - 1: no A issue of this tile is left; the A base moves on to the next tile
+                cur.a = base_a(tm_n);
+                dma4(cur.a, cur.oa, smem + a_off(nk, 0) + dma_off);
+            }
+        };
+        auto l1_issue_wait = [&](int kt) {
+            if (kt + 2 < nk) {
+                issue_w(kt + 2);
+                pp_wait_vmcnt<8>();   // all but A(k+1) | W(k+2) (AST 3: A(k+2), W(k+2)) => W(k+1) landed
+            } else if (has_next) {
+                if (kt + 2 == nk) {   // no W issue of this tile is left; the W base moves on to the next tile
+                    cur.w = base_w(tn_n);
+                    dma4(cur.w, cur.oa, smem + w_off(nk) + dma_off);
+                } else {
+                    dma4(cur.w + KT_BYTES, cur.oa, smem + w_off(nk + 1) + dma_off);
+                }
+                pp_wait_vmcnt<8>();
+            } else if (AST == 2 && kt + 1 < nk) {
+                pp_wait_vmcnt<4>();
+            } else {
+                pp_wait_vmcnt<0>();
+            }
+        };
+        auto c1_wait = [&](int kt) {
+            if (AST == 2) {
+                if (kt + 2 < nk || has_next) pp_wait_vmcnt<4>();   // all but W(k+2) => A(k+1) landed
+                else pp_wait_vmcnt<0>();
+            }
+        };
 
         if constexpr (F8) {
             i32x8 wf[NI], xf[MI / 2];
@@ -229,8 +307,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                 for (int ni = 0; ni < NI; ++ni) wf[ni] = ld8(sw + ni * 2048);
 #pragma unroll
                 for (int mi = 0; mi < MI / 2; ++mi) xf[mi] = ld8(sa + mi * 2048);
-                if (AST == 3) { if (kt + 2 < nk) issue_a(kt + 2, k3 == 0 ? 2 : k3 - 1); }
-                else if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
+                l0_issue(kt, k3);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 pp_barrier();
                 // ---- C0 ----
@@ -245,14 +322,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                 // ---- L1 ----
 #pragma unroll
                 for (int mi = 0; mi < MI / 2; ++mi) xf[mi] = ld8(sa + (MI / 2 + mi) * 2048);
-                if (kt + 2 < nk) {
-                    issue_w(kt + 2);
-                    pp_wait_vmcnt<8>();   // AST 3: all but A(k+2), W(k+2) => A(k+1) and W(k+1) landed
-                } else if (AST == 2 && kt + 1 < nk) {
-                    pp_wait_vmcnt<4>();
-                } else {
-                    pp_wait_vmcnt<0>();
-                }
+                l1_issue_wait(kt);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 pp_barrier();
                 // ---- C1 ----
@@ -263,10 +333,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                     for (int ni = 0; ni < NI; ++ni)
                         acc[MI / 2 + mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf[mi], acc[MI / 2 + mi][ni], 0, 0, 0, unit, 0, unit);
                 __builtin_amdgcn_s_setprio(0);
-                if (AST == 2) {
-                    if (kt + 2 < nk) pp_wait_vmcnt<4>();
-                    else pp_wait_vmcnt<0>();
-                }
+                c1_wait(kt);
                 pp_barrier();
             }
         } else {
@@ -282,8 +349,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(sa + mi * 2048 + off0);
-            if (AST == 3) { if (kt + 2 < nk) issue_a(kt + 2, k3 == 0 ? 2 : k3 - 1); }
-            else if (kt >= 1 && kt + 1 < nk) issue_a(kt + 1);
+            l0_issue(kt, k3);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             pp_barrier();
             // ---- C0 ------------------------------------------------------------------------------------------------
@@ -297,14 +363,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // ---- L1 ------------------------------------------------------------------------------------------------
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(sa + mi * 2048 + off1);
-            if (kt + 2 < nk) {
-                issue_w(kt + 2);
-                pp_wait_vmcnt<8>();   // AST 3: all but A(k+2), W(k+2) => A(k+1) and W(k+1) landed
-            } else if (AST == 2 && kt + 1 < nk) {
-                pp_wait_vmcnt<4>();
-            } else {
-                pp_wait_vmcnt<0>();
-            }
+            l1_issue_wait(kt);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             pp_barrier();
             // ---- C1 ------------------------------------------------------------------------------------------------
@@ -314,10 +373,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf1[ni], xf[mi], acc[mi][ni]);
             __builtin_amdgcn_s_setprio(0);
-            if (AST == 2) {
-                if (kt + 2 < nk) pp_wait_vmcnt<4>();
-                else pp_wait_vmcnt<0>();
-            }
+            c1_wait(kt);
             pp_barrier();
         }
         }
@@ -329,48 +385,63 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         // ---- tile boundary --------------------------------------------------------------------------------------
         const int m_w = tile_m * BM + grp * 128, n_w = tile_n * BN + wn * 64;
         const bool m_full = (tile_m + 1) * BM <= M, n_full = (tile_n + 1) * BN <= N;
-        const int t_next = t + stride;
-        const bool has_next = PERSIST && t_next < ntiles;
-        if (has_next) {
-            setup_tile(t_next);
-            issue_w(0);  // next tile's K-tile 0 -> stage 0 while the epilogue runs out of stage 1
-            issue_a(0);
-        }
+        // one tile per workgroup: the epilogue stages through the (idle) stage 1; persistent: through its own region
+        char* const stage_epi = smem + (PERSIST ? 2 * STAGE_BYTES : STAGE_BYTES);
         const EpiArgs e{bias, outp, M, N, aux, aux_i, stats, out16, partials};
+        // Everything the epilogue derives from the lane id is derived HERE, per tile: in the persistent form the compiler
+        // would otherwise hoist those lane-constant addresses out of the tile loop and keep them alive through the K loop,
+        // which has no register to spare (spills inside the K loop are vector-memory operations: they would break its
+        // counted waits).
+        int lane_e = lane;
+        if constexpr (PERSIST) asm volatile("" : "+v"(lane_e));
         if constexpr (F8) {
-            // per-output-channel weight scale (`aux`): the lane's 4 consecutive columns of column block ni
+            // per-output-channel weight scale (`aux`): the lane's 4 consecutive columns of column block ni.  The product is
+            // rounded on its own (no contraction with the epilogue's "+ bias" into an fma): every form of the kernel then
+            // produces the same bits, whatever the compiler's inlining context makes of the two statements.
+#pragma clang fp contract(off)
+            const int fq_e = lane_e >> 4;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int n = n_w + ni * 16 + fq * 4;
+                const int n = n_w + ni * 16 + fq_e * 4;
                 const f32x4 ws = n < N ? *(const f32x4*)(aux + n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = acc[mi][ni] * ws;
             }
         }
-        if constexpr (F8 && EPI == VH_EPI_BIAS_GELU)
-            gemm_epilogue8<EPI, MI, NI, VH_PP_SMI>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);
-        else
-            gemm_epilogue<T, EPI, MI, NI, (epi_is_16bit(EPI) ? VH_PP_SMI : 4), false>(acc, e, m_w, n_w, lane, n_full, m_full, smem + STAGE_BYTES, wave);   // fp32 forms: 32 rows per pass
+        if constexpr (PERSIST) {
+            // full tiles only: ONE straight-line staged epilogue.  (With a ragged variant beside it hipcc hoisted the shared
+            // leading load above the branch between the two, saw a path on which it is never waited for, and drained the
+            // DMA queue -- vmcnt(0) -- before the next tile's first fragment reads overwrote its register.)
+            constexpr int SLICE = VH_PP_SMI * 16 * 128;
+            if constexpr (F8 && EPI == VH_EPI_BIAS_GELU)
+                gemm_epilogue8<EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, true, stage_epi, wave);
+            else
+                gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
+        } else {
+            if constexpr (F8 && EPI == VH_EPI_BIAS_GELU)
+                gemm_epilogue8<EPI, MI, NI, VH_PP_SMI>(acc, e, m_w, n_w, lane_e, n_full, stage_epi, wave);
+            else
+                gemm_epilogue<T, EPI, MI, NI, (epi_is_16bit(EPI) ? VH_PP_SMI : 4), false>(acc, e, m_w, n_w, lane_e, n_full, m_full, stage_epi, wave);   // fp32 forms: 32 rows per pass
+        }
 #ifdef VH_DIAG_STAMPS
+        if (first_tile_) VH_STAMP(3, diag_rt());
+        if (!has_next && first_tile_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores drained (one tile per workgroup)
         if (first_tile_) {
-            VH_STAMP(3, diag_rt());
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             VH_STAMP(4, diag_rt());
             st_[7] = diag_hwid();
-            if (stamps && threadIdx.x == 0) {
+            if (stamps && lane == 0) {   // one record per wave
 #pragma unroll
-                for (int i = 0; i < 8; ++i) stamps[(size_t)blockIdx.x * 8 + i] = st_[i];
+                for (int i = 0; i < 8; ++i) stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = st_[i];
             }
-            first_tile_ = false;
         }
+        ++it_;
 #endif
         if (!has_next) break;
-        if (nk > 1) {
-            pp_barrier();  // every wave is done with its staging slice of stage 1
-            issue_w(1);
-            issue_a(1, 1);
-        }
+        par = (par + nk) & 1;
+        first = false;
         t = t_next;
+        tile_m = tm_n;
+        tile_n = tn_n;
     }
 }
 
@@ -387,6 +458,13 @@ static int gemm_super_columns(int tiles_n) {
     return 4;
 }
 
+// start phases of the persistent workgroups (VH_PP_STAGGER, 0 / 1 = none)
+static int gemm_stagger() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VH_PP_STAGGER"); v = e ? atoi(e) : 0; if (v < 0 || v > 64) v = 0; }
+    return v;
+}
+
 #ifdef VH_DIAG_STAMPS
 // ring of the most recent launches' stamps (host bookkeeping; one device buffer of slots x max_wgs x 8 words)
 struct DiagRec { int64_t M; int N, K, epi, f8, grid, variant; };
@@ -399,7 +477,7 @@ static unsigned long long* diag_next(const GemmArgs& g, int epi, bool f8, int gr
     const int slot = (int)(g_diag_count % g_diag_slots);
     g_diag_rec[slot] = DiagRec{g.M, g.N, g.K, epi, f8 ? 1 : 0, grid, variant};
     ++g_diag_count;
-    return g_diag_buf + (size_t)slot * g_diag_max_wgs * 8;
+    return g_diag_buf + (size_t)slot * g_diag_max_wgs * 64;
 }
 #define VH_STAMP_ARG(g, epi, f8, grid, variant) , diag_next(g, epi, f8, grid, variant)
 #else
@@ -409,18 +487,20 @@ static unsigned long long* diag_next(const GemmArgs& g, int epi, bool f8, int gr
 // mode 0: one tile per workgroup (variant 5); 1: persistent (6); 2: one tile per workgroup, three A stages (7)
 template <typename T, int EPI, bool F8, bool PERSIST, int AST>
 static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int tiles_n, hipStream_t s) {
-    constexpr size_t lds = AST == 3 ? 163840 : 131072;
+    constexpr size_t lds = (AST == 3 || PERSIST) ? 163840 : 131072;
     auto k = gemm_nt_pp_kernel<T, EPI, PERSIST, F8, AST>;
     static int lds_done[kMaxDevices] = {0};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
-                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n)
+                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n),
+                       PERSIST ? gemm_stagger() : 0
                        VH_STAMP_ARG(g, EPI, F8, grid, PERSIST ? 6 : (AST == 3 ? 7 : 5)));
     return hipGetLastError();
 }
 
 template <typename T, int EPI, bool F8>
 static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
+    if constexpr (!epi_is_16bit(EPI)) { if (mode == 1) mode = 0; }   // see below
     const int tiles_m = (int)((g.M + 255) / 256), tiles_n = (g.N + 255) / 256;
     int ntiles = tiles_m * tiles_n;
     if (g.tile_count > 0) {   // a sub-range of the tiles (one tile per workgroup forms only)
@@ -430,7 +510,15 @@ static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
         return hipErrorInvalidValue;
     }
     if (mode == 2) return launch_pp_one<T, EPI, F8, false, 3>(g, ntiles, tiles_m, tiles_n, s);
-    if constexpr (!F8) {
+    // persistent form: 16-bit-result epilogues only (the fp32 read-modify-write epilogues do not fit the register file in
+    // that form: spill reloads inside the K loop are vector-memory operations and would break its counted waits), so a
+    // request for it with another epilogue takes the one-tile-per-workgroup form
+    if constexpr (epi_is_16bit(EPI)) {
+        // the persistent form runs FULL tiles of at least two K-tiles only: N must be a multiple of the tile, and a ragged
+        // last row of tiles (M % 256 != 0) goes to the one-tile-per-workgroup form as a tile range behind it
+        const int full_m = (int)(g.M / 256);
+        const int nk = g.K / (F8 ? 128 : 64);
+        if (mode == 1 && (g.N % 256 != 0 || full_m == 0 || nk < 2)) mode = 0;
         if (mode == 1) {
             static int num_cu = 0;
             if (!num_cu) {
@@ -439,7 +527,13 @@ static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
                 if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
                 num_cu = prop.multiProcessorCount;
             }
-            return launch_pp_one<T, EPI, F8, true, 2>(g, ntiles < num_cu ? ntiles : num_cu, tiles_m, tiles_n, s);
+            const int nfull = full_m * tiles_n;
+            if (hipError_t e = launch_pp_one<T, EPI, F8, true, 2>(g, nfull < num_cu ? nfull : num_cu, full_m, tiles_n, s); e != hipSuccess) return e;
+            if (full_m == tiles_m) return hipSuccess;
+            GemmArgs tail = g;   // tiles [full_m * tiles_n, ntiles) of the n-fastest order = the ragged last row of tiles
+            tail.tile_begin = nfull;
+            tail.tile_count = tiles_n;
+            return launch_pp_one<T, EPI, F8, false, 2>(tail, tiles_n, tiles_m, tiles_n, s);
         }
     }
     return launch_pp_one<T, EPI, F8, false, 2>(g, ntiles, tiles_m, tiles_n, s);
@@ -464,11 +558,13 @@ VH_INST(FP16)
 
 // fp8 operands: 16-bit results are bf16; fc1 writes e4m3 (gemm_epilogue8)
 hipError_t launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
+    const int v = g.variant ? g.variant : gemm_pp_variant(g.epilogue);
+    const int mode = v == 7 ? 2 : (v == 6 && !g.tile_count && !g.tile_begin ? 1 : 0);
     switch (g.epilogue) {
-        case VH_EPI_BIAS: return launch_pp<BF16, VH_EPI_BIAS, true>(g, (g.variant ? g.variant : gemm_pp_variant()) == 7 ? 2 : 0, s);
-        case VH_EPI_BIAS_GELU: return launch_pp<BF16, VH_EPI_BIAS_GELU, true>(g, (g.variant ? g.variant : gemm_pp_variant()) == 7 ? 2 : 0, s);
-        case VH_EPI_BIAS_RESID: return launch_pp<BF16, VH_EPI_BIAS_RESID, true>(g, (g.variant ? g.variant : gemm_pp_variant()) == 7 ? 2 : 0, s);
-        case VH_EPI_BIAS_F32: return launch_pp<BF16, VH_EPI_BIAS_F32, true>(g, (g.variant ? g.variant : gemm_pp_variant()) == 7 ? 2 : 0, s);
+        case VH_EPI_BIAS: return launch_pp<BF16, VH_EPI_BIAS, true>(g, mode, s);
+        case VH_EPI_BIAS_GELU: return launch_pp<BF16, VH_EPI_BIAS_GELU, true>(g, mode, s);
+        case VH_EPI_BIAS_RESID: return launch_pp<BF16, VH_EPI_BIAS_RESID, true>(g, mode == 1 ? 0 : mode, s);
+        case VH_EPI_BIAS_F32: return launch_pp<BF16, VH_EPI_BIAS_F32, true>(g, mode == 1 ? 0 : mode, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -481,12 +577,12 @@ extern "C" int vh_diag_stamps_arm(int slots, int max_wgs) {
     using namespace vh;
     if (slots < 1 || slots > 1024 || max_wgs < 1) return 1;
     if (g_diag_buf) { hipFree(g_diag_buf); g_diag_buf = nullptr; }
-    if (hipMalloc((void**)&g_diag_buf, (size_t)slots * max_wgs * 64) != hipSuccess) return 2;
-    if (hipMemset(g_diag_buf, 0, (size_t)slots * max_wgs * 64) != hipSuccess) return 2;
+    if (hipMalloc((void**)&g_diag_buf, (size_t)slots * max_wgs * 512) != hipSuccess) return 2;
+    if (hipMemset(g_diag_buf, 0, (size_t)slots * max_wgs * 512) != hipSuccess) return 2;
     g_diag_slots = slots; g_diag_max_wgs = max_wgs; g_diag_count = 0;
     return 0;
 }
-// age 0 = the most recent launch; copies grid x 8 words; meta = {M, N, K, epi, f8, grid, variant}
+// age 0 = the most recent launch; copies grid x 8 waves x 8 words; meta = {M, N, K, epi, f8, grid, variant}
 extern "C" int vh_diag_stamps_read(int age, unsigned long long* host, int max_wgs, long long* meta) {
     using namespace vh;
     if (!g_diag_buf || age < 0 || age >= g_diag_slots || age >= g_diag_count) return 1;
@@ -494,7 +590,7 @@ extern "C" int vh_diag_stamps_read(int age, unsigned long long* host, int max_wg
     const int slot = (int)((g_diag_count - 1 - age) % g_diag_slots);
     const DiagRec& r = g_diag_rec[slot];
     if (r.grid > max_wgs) return 3;
-    if (hipMemcpy(host, g_diag_buf + (size_t)slot * g_diag_max_wgs * 8, (size_t)r.grid * 64, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    if (hipMemcpy(host, g_diag_buf + (size_t)slot * g_diag_max_wgs * 64, (size_t)r.grid * 512, hipMemcpyDeviceToHost) != hipSuccess) return 2;
     meta[0] = r.M; meta[1] = r.N; meta[2] = r.K; meta[3] = r.epi; meta[4] = r.f8; meta[5] = r.grid; meta[6] = r.variant;
     return 0;
 }

@@ -403,7 +403,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
                              const float* lnb, int st_gemm) -> int {
         const int tiles_n = (D + 255) / 256, ntile = (int)((rows + 255) / 256) * tiles_n;
         int split = 0;
-        const bool pp = c->fp8 || gemm_pick_variant(rows, D) == 5 || gemm_pick_variant(rows, D) == 7;
+        const bool pp = c->fp8 || gemm_pick_variant(rows, D, VH_EPI_BIAS_RESID) == 5 || gemm_pick_variant(rows, D, VH_EPI_BIAS_RESID) == 7;
         if (allow_tail && c->tail_overlap && lnw && !ev && pp && ntile > c->num_cu && ntile % c->num_cu != 0 &&
             c->timing_stage != ST_LN && c->timing_stage != ST_PROJ && c->timing_stage != ST_FC2) {
             split = ntile / c->num_cu * c->num_cu;
@@ -1219,7 +1219,7 @@ int vh_op_gemm(const void* a, const void* w, const float* bias, void* out, int64
 }
 int vh_op_gemm_fp8(const void* a8, const void* w8, const float* w_scale, const float* bias, void* out, int64_t M, int N, int K,
                    int epi, int variant, void* stream) {
-    if (variant != 0 && variant != 5 && variant != 7) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: variant must be 0, 5 or 7");
+    if (variant != 0 && variant != 5 && variant != 6 && variant != 7) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: variant must be 0, 5, 6 or 7");
     if (!a8 || !w8 || !w_scale || !bias || !out) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: null pointer");
     if (M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 4) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: need K %% 128 == 0 and N %% 4 == 0");
     if (M > 0x7FFFFFFF / 2) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8: M too large");
