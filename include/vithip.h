@@ -72,8 +72,16 @@ typedef struct vh_config {
     int32_t dtype;      /* VH_DTYPE_*                                      */
     int32_t max_batch;  /* workspace is sized for this many images         */
     float ln_eps;       /* 1e-6 for the canonical ViT                      */
-    int32_t reserved;   /* must be 0                                       */
+    int32_t flags;      /* VH_FLAG_* (0 = library defaults); unknown bits are rejected */
 } vh_config;
+
+/* vh_config.flags.  LayerNorm folding: with dim and mlp_dim multiples of 256 the two LayerNorms of a layer are folded
+ * into the neighbouring GEMMs by default (DESIGN.md "LayerNorm folded into the GEMMs"): the GEMM then multiplies the
+ * RAW 16-bit-rounded residual rows.  The choice depends on the model shape and these flags ONLY (never on max_batch),
+ * so a given image gives the same logit bits from every context of one configuration.  The folded operand's rounding
+ * error grows with |row mean| / row sigma; for activations with a large common-mode offset choose VH_FLAG_LN_FOLD_OFF. */
+#define VH_FLAG_LN_FOLD_OFF 1 /* always run the stand-alone LayerNorm kernel                */
+#define VH_FLAG_LN_FOLD_ON 2  /* fold where the shapes allow it (the default, stated explicitly) */
 
 typedef struct vh_ctx vh_ctx; /* opaque ViT context (device, stream, weights, workspace) */
 typedef struct vh_mlp vh_mlp; /* opaque MLP-mode context (the reference's real semantics)  */
@@ -100,6 +108,8 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out);
 /* replaces cleanup() + ~net_fpga (netFPGA.cpp:613-651); frees ALL device memory. */
 int vh_destroy(vh_ctx* ctx);
 int vh_get_config(const vh_ctx* ctx, vh_config* out);
+/* *on = 1 when this context folds its LayerNorms into the GEMMs (vh_config.flags, model shape, dtype) */
+int vh_get_ln_fold(const vh_ctx* ctx, int* on);
 
 /* Weight blob = fp32 tensors in canonical order (DESIGN.md "weight blob") preceded by a
  * 64-byte header.  Replaces _load_params (netFPGA.cpp:484-515): uploads, converts to the
@@ -123,6 +133,9 @@ int vh_export_weights_device(vh_ctx* ctx, void* dev_blob, size_t nbytes);
  *                        fields of *cfg (dtype = VH_DTYPE_BF16, max_batch = 1: set what you need before vh_create);
  *   vh_save_weights_file: writes <path>.tmp then renames; vh_load_weights_file: verifies length, shape, checksum. */
 int vh_blob_file_config(const char* path, vh_config* cfg);
+/* host only: the file as a MEMORY blob (what vh_load_weights takes): length, header and checksum verified, checksum
+ * words cleared.  nbytes must equal vh_weight_blob_bytes of the file's configuration. */
+int vh_blob_file_read(const char* path, void* host_blob, size_t nbytes);
 int vh_save_weights_file(vh_ctx* ctx, const char* path);
 int vh_load_weights_file(vh_ctx* ctx, const char* path);
 
@@ -263,6 +276,34 @@ int vh_op_fill(float* out_dev, int64_t n, uint64_t seed, uint32_t tensor_id, int
  * generated in HBM (uniform[-1,1) activations, sigma=0.02 weights), `iters` launches between events */
 int vh_bench_gemm(int device, int64_t M, int N, int K, int epilogue, int dtype, int variant, int iters,
                   double* avg_ms);
+
+/* ---- device group: the N GPUs of one node from ONE process ---------------------------------------------------------
+ * The reference drives a single device (clGetDeviceIDs(CL_DEVICE_TYPE_ACCELERATOR), netFPGA.cpp:376) with one input
+ * vector per call (:266-277) and has no multi-device code; this is the C-ABI form of the image sharding the north star
+ * asks for: one context + one host thread + one stream per device, ncclCommInitAll, ONE ncclBroadcast of the canonical
+ * weight blob from member 0 over xGMI (the per-device upload of _load_params, netFPGA.cpp:484-515), contiguous image
+ * ranges per member, per-member D2H into the caller's logits buffer; no collective on the data path.  RCCL is loaded at
+ * run time and only for groups of more than one distinct device.  Listing one ordinal several times gives a REHEARSAL
+ * group on one GPU (same threads, shards and blob path; the broadcast is a device-to-device copy).
+ * cfg->max_batch is the per-device capacity.  A group is not re-entrant. */
+typedef struct vh_group vh_group;
+int vh_group_create(const vh_config* cfg, const int* devices, int n, vh_group** out);
+int vh_group_destroy(vh_group* g);
+int vh_group_size(const vh_group* g, int* n);
+int vh_group_member(vh_group* g, int i, vh_ctx** ctx, int* device); /* the member's own context (borrowed) */
+const char* vh_group_last_error(const vh_group* g);
+/* image range [lo, hi) of member r for a batch split over n members (the first batch % n members take one extra) */
+void vh_group_shard_bounds(int batch, int n, int r, int* lo, int* hi);
+/* weights: loaded / generated on member 0, then broadcast; vh_group_broadcast_weights re-sends member 0's resident blob */
+int vh_group_load_weights(vh_group* g, const void* host_blob, size_t nbytes);
+int vh_group_init_weights_seeded(vh_group* g, uint64_t seed);
+int vh_group_broadcast_weights(vh_group* g);
+/* the hot path over the group (same buffers and meaning as vh_forward): synchronous, all members run concurrently */
+int vh_group_forward(vh_group* g, const float* in_nhwc_host, int batch, float* logits_host);
+/* measurement path with the inputs resident in every member's HBM (member i = shard i, seed + i) */
+int vh_group_fill_inputs_seeded(vh_group* g, uint64_t seed, int batch_per_device);
+int vh_group_forward_resident(vh_group* g, int batch_per_device, int steps);
+int vh_group_read_logits(vh_group* g, int batch_per_device, float* logits_host); /* [n * batch_per_device, classes] */
 
 /* ---- filter_image pipeline -------------------------------------------------------------------
  * The reference's second device entry: single-channel 8-bit frames (1080 x 1920, defines.h:31-38) pushed through

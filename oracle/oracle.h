@@ -60,8 +60,8 @@ int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float
 int oracle_vit_forward_fp8(const oracle_vit_config* c, const void* blob, const float* in_nhwc,
                            int batch, float* logits, float* hidden, int n_layers_run, int threads);
 /* The fp32 forward with the device's 16-bit ROUNDING POINTS emulated one by one (dtype 0 = bf16, 1 = fp16; mask bits:
- * 1 weights, 2 LayerNorm output, 4 q|k|v, 8 softmax probabilities, 16 attention output, 32 GELU output, 64 patch
- * matrix, 128 final-LN'd CLS rows, 256 LayerNorm folded into q|k|v / fc1 instead of bit 2).  Accumulation, residual
+ * 1 patch and per-layer weights, 2 LayerNorm output, 4 q|k|v, 8 softmax probabilities, 16 attention output, 32 GELU
+ * output, 64 patch matrix, 128 final-LN'd CLS rows, 512 head weights, 256 LayerNorm folded into q|k|v / fc1 instead of bit 2).  Accumulation, residual
  * stream and statistics stay fp32.  Attributes the device's distance from the fp32 oracle to its MFMA operand
  * roundings (tools/parity_attribution.py, DESIGN.md "Numerics"). */
 int oracle_vit_forward_emul16(const oracle_vit_config* c, const void* blob, const float* in_nhwc, int batch,

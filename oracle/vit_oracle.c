@@ -359,8 +359,8 @@ static void linear_scaled(const float* a, const float* wq, const float* scale, c
 
 /* emul16: 0 = plain fp32; else 1 + dtype (1 = bf16, 2 = fp16) with `mask` choosing WHICH tensors are rounded to that
  * 16-bit type on their way into a matrix product, i.e. where the device (vit-fpga_amd/csrc) holds an MFMA operand:
- *   1 weights   2 LayerNorm output   4 q|k|v   8 softmax probabilities   16 attention output   32 GELU output
- *   64 patch matrix   128 final-LN'd CLS rows   256 = LayerNorm FOLDED into q|k|v and fc1 (vithip_api.hip prepare_weights:
+ *   1 weights (patch + per-layer matrices)   2 LayerNorm output   4 q|k|v   8 softmax probabilities   16 attention output
+ *   32 GELU output   64 patch matrix   128 final-LN'd CLS rows   512 head weights   256 = LayerNorm FOLDED into q|k|v and fc1 (vithip_api.hip prepare_weights:
  *   operand = the rounded RAW residual, weights = round(gamma o W), out = rstd (acc - mean c) + d) instead of bit 2.
  * Everything else (accumulation, residual stream, statistics) stays fp32, as on the device.  Used to ATTRIBUTE the
  * device's distance from the fp32 forward to its rounding points (tools/parity_attribution.py). */
@@ -565,7 +565,7 @@ static int vit_forward_impl(const oracle_vit_config* c, const void* blob, const 
     for (int b = 0; b < batch; ++b)
         oracle_layernorm(x + (int64_t)b * T * D, 1, D, fin, fin + D, c->ln_eps, y + (int64_t)b * D);
     if (EM(128)) round16_buf(y, (int64_t)batch * D, edt);
-    if (EM(1)) {
+    if (EM(512)) {
         memcpy(wtmp, fin + 2 * D, sizeof(float) * (size_t)C * D);
         round16_buf(wtmp, (int64_t)C * D, edt);
         oracle_linear(y, wtmp, fin + 2 * D + (size_t)C * D, logits, batch, C, D);

@@ -148,6 +148,31 @@ static void gpu_checks()
     CHECK(r1.size() == 40 && std::equal(r1.begin(), r1.end(), got2.begin()));
     CHECK(seeded.collect_forward().empty());
     CHECK(seeded.launch_forward(img) == got2);               // the synchronous call still works next to the pipeline
+    // a larger batch would re-create the context: refused while a batch is still in the ring, fine once it is collected
+    CHECK(seeded.submit_forward(one));
+    std::vector<float> big(img);
+    big.insert(big.end(), img.begin(), img.end());
+    bool refused = false;
+    try { seeded.launch_forward(big); } catch (const std::exception &) { refused = true; }
+    CHECK(refused);
+    CHECK(seeded.collect_forward().size() == 40);
+    const std::vector<float> rb = seeded.launch_forward(big);
+    CHECK(rb.size() == 2 * got2.size() && std::equal(got2.begin(), got2.end(), rb.begin()) && std::equal(got2.begin(), got2.end(), rb.begin() + got2.size()));
+
+    // ---- device list: the same net_abstract* shards its batch over a device group (here a rehearsal group: GPU 0 listed
+    //      three times = three contexts, three host threads, blob broadcast by device copy); same logits, bit for bit ----
+    {
+        hip::net_hip many(c, 77);
+        many.set_devices(std::vector<int>{0, 0, 0});
+        CHECK(many.device_count() == 3);
+        CHECK(many.launch_forward(img) == got2);
+        CHECK(many.launch_forward(one) == std::vector<float>(got2.begin(), got2.begin() + 40));   // fewer images than members
+        std::vector<float> seven;
+        for (int r = 0; r < 7; ++r) seven.insert(seven.end(), one.begin(), one.end());
+        const std::vector<float> r7 = many.launch_forward(seven);                                 // ragged shards 3 | 2 | 2
+        CHECK(r7.size() == 7 * 40);
+        for (int r = 0; r < 7; ++r) CHECK(std::equal(r7.begin() + 40 * r, r7.begin() + 40 * (r + 1), got2.begin()));
+    }
 
     // ---- weights on disk: save, re-create from the file alone, same logits ----
     const char *path = "/tmp/test_net_hip.vhblob";
@@ -158,6 +183,15 @@ static void gpu_checks()
     bool threw = false;
     try { hip::net_hip::from_file("/tmp/does_not_exist.vhblob", VH_DTYPE_FP16); } catch (const std::exception &) { threw = true; }
     CHECK(threw);
+    // a damaged payload byte: from_file verifies the checksum (as vh_load_weights_file does) instead of loading it
+    {
+        FILE *f = fopen(path, "r+b");
+        CHECK(f != nullptr);
+        if (f) { fseek(f, 4096, SEEK_SET); int ch = fgetc(f); fseek(f, 4096, SEEK_SET); fputc(ch ^ 1, f); fclose(f); }
+        threw = false;
+        try { hip::net_hip::from_file(path, VH_DTYPE_FP16); } catch (const std::exception &) { threw = true; }
+        CHECK(threw);
+    }
     remove(path);
 
     // ---- filter_image / get_filtered_image: 24 frames in flight, the 25th is dropped, FIFO results ----

@@ -125,7 +125,7 @@ def vit_forward(cfg, blob, images, n_layers=-1, threads=0, want_hidden=False, ln
 
 
 EMUL_BITS = {"weights": 1, "ln_out": 2, "qkv": 4, "probs": 8, "attn_out": 16, "gelu_out": 32, "patches": 64, "cls_rows": 128,
-             "ln_folded": 256}
+             "head_weights": 512, "ln_folded": 256}
 
 
 def vit_forward_emul16(cfg, blob, images, dtype, mask, threads=0, ln_eps=1e-6):

@@ -47,9 +47,12 @@ def test_tools_and_entry_points_compile():
     # the measurement scripts are part of the evidence trail (profiles/README.md names them): keep them importable
     import py_compile
     for rel in ("bench.py", "__graft_entry__.py", "tools/soak.py", "tools/parity_stats.py", "tools/pmc_summary.py",
-                "tools/gemm_bench.py", "tools/tiles_exp.py", "tools/fold_parity.py", "tests/golden/make_golden.py"):
+                "tools/gemm_bench.py", "tools/tiles_exp.py", "tools/fold_parity.py", "tests/golden/make_golden.py",
+                "tools/gemm_anatomy.py", "tools/torch_matmul_calib.py", "tools/parity_attribution.py", "tools/pmc_traffic.py",
+                "tests/cpu_leg.py"):
         py_compile.compile(os.path.join(ROOT, rel), doraise=True)
-    for rel in ("tools/power_probe.sh", "tools/ab_variant7.sh", "tools/ab_tail.sh", "tools/ab_supercol.sh", "tools/ab_attn.sh"):
+    for rel in ("tools/power_probe.sh", "tools/ab_variant7.sh", "tools/ab_tail.sh", "tools/ab_supercol.sh", "tools/ab_attn.sh",
+                "tools/pmc_passes.sh"):
         subprocess.check_call(["bash", "-n", os.path.join(ROOT, rel)])
 
 
@@ -57,7 +60,7 @@ def test_no_torch_or_oracle_dependency_in_the_product_library():
     out = subprocess.check_output(["readelf", "-d", vithip.LIB_PATH], text=True)
     needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
     assert any("amdhip64" in n for n in needed)
-    assert not any(("torch" in n) or ("oracle" in n) or ("c10" in n) for n in needed), needed
+    assert not any(("torch" in n) or ("oracle" in n) or ("c10" in n) or ("rccl" in n) for n in needed), needed   # RCCL: dlopen, groups of > 1 only
     src = os.path.join(ROOT, "vit-fpga_amd")
     for dirpath, _, files in os.walk(src):
         for f in files:
@@ -98,3 +101,24 @@ def test_host_side_16bit_helpers():
                           np.array([1.0, 1.0, 1.015625, -2.5, 0.0], dtype=np.float32))
     assert np.array_equal(vithip.from16(vithip.to16(x, vithip.DTYPE_FP16), vithip.DTYPE_FP16)[:2],
                           np.array([1.0, 1.00390625], dtype=np.float32))
+
+
+def test_group_shard_bounds_match_the_multi_process_sharding():
+    """vh_group_shard_bounds (C ABI, single process) and vh_dist.shard_bounds (one process per GPU) split a batch the same
+    way; together the shards cover the batch exactly once."""
+    import vh_dist
+    for batch, n in ((4096, 8), (10, 3), (2, 4), (7, 7), (1, 1), (513, 2)):
+        cover = []
+        for r in range(n):
+            lo, hi = vithip.group_shard_bounds(batch, n, r)
+            assert (lo, hi) == vh_dist.shard_bounds(batch, n, r)
+            cover += list(range(lo, hi))
+        assert cover == list(range(batch))
+
+
+def test_group_create_without_a_device_fails_loudly():
+    if vithip.device_count() > 0:
+        pytest.skip("a device is present")
+    with pytest.raises(vithip.VhError) as e:
+        vithip.VitGroup(S.CONFIGS["vit_micro"], [0, 1])
+    assert e.value.code == 5   # VH_ERR_NO_DEVICE

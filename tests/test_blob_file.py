@@ -21,9 +21,28 @@ def test_file_header_is_validated_on_the_host(tmp_path):
     np.concatenate([blob, blob[:8]]).tofile(tmp_path / "long.vhblob")
     odd = blob.copy(); odd[8 + 12:8 + 16] = np.frombuffer(np.int32(100).tobytes(), np.uint8)   # dim = 100: unsupported
     odd.tofile(tmp_path / "dim.vhblob")
+    # a crafted header: absurd layer / class / image counts must be refused from the header alone (no allocation is driven
+    # by the file: the bounds of check_config apply before any size is computed), never abort the process
+    for off, val in ((8 + 24, 2 ** 31 - 1), (8 + 24, 5000), (8 + 28, 2 ** 30), (8 + 0, 2 ** 20), (8 + 20, 2 ** 24)):
+        crafted = blob.copy(); crafted[off:off + 4] = np.frombuffer(np.int32(val).tobytes(), np.uint8)
+        crafted.tofile(tmp_path / f"crafted_{off}_{val}.vhblob")
+        with pytest.raises(vithip.VhError):
+            vithip.blob_file_config(tmp_path / f"crafted_{off}_{val}.vhblob")
     for name in ("magic", "short", "long", "dim", "missing"):
         with pytest.raises(vithip.VhError):
             vithip.blob_file_config(tmp_path / f"{name}.vhblob")
+    # vh_blob_file_read: the file as a memory blob, checksum verified when present
+    buf = np.empty(blob.size, np.uint8)
+    assert vithip.lib().vh_blob_file_read(str(good).encode(), buf.ctypes.data, buf.size) == 0 and np.array_equal(buf, blob)
+    assert vithip.lib().vh_blob_file_read(str(good).encode(), buf.ctypes.data, buf.size - 4) != 0
+
+
+def test_weight_blob_size_formula_matches_the_layout():
+    for name, cfg in S.CONFIGS.items():
+        c = vithip.make_config(cfg)
+        assert vithip.lib().vh_weight_blob_bytes(c) == 64 + 4 * S.param_count(cfg), name
+    bad = vithip.make_config(S.CONFIGS["vit_micro"], flags=64)       # unknown flag bits are rejected
+    assert vithip.lib().vh_weight_blob_bytes(bad) == 0
 
 
 @pytest.mark.gpu

@@ -4,11 +4,14 @@ independent fp64 implementation).
 
 Tolerance.  The north star asks for logits within 1e-3 (relative, fp32 reference).  The metric used
 here is  max|logit_gpu - logit_ref| / max|logit_ref|  over the whole batch.
-  * fp16 MFMA operands (11-bit significand): asserted at 1e-3.
-  * bf16 MFMA operands (8-bit significand), the dtype BASELINE.json's headline config names:
-    asserted at 1e-2 (measured 4e-3..6.4e-3).  1e-3 is not reachable with bf16 operand rounding (each GEMM input carries
-    ~2^-9 relative rounding error; measured values are recorded in DESIGN.md) even with the fp32
-    residual stream, fp32 LayerNorm/softmax statistics and fp32 accumulation this build keeps.
+  * fp16 MFMA operands (11-bit significand): asserted at 1e-3 = THE NORTH STAR'S TOLERANCE, on every model, on 32 ViT-B
+    images with both LayerNorm paths, and on ViT-L/16 at 384x384.
+  * bf16 MFMA operands (8-bit significand), the dtype BASELINE.json's headline config names: OUTSIDE the north star's
+    tolerance by construction -- each GEMM input carries ~2^-9 relative rounding error and the measured distance is
+    4e-3..7.5e-3, eight times the fp16 figure, exactly the ratio of the two significands -- even with the fp32
+    residual stream, fp32 LayerNorm/softmax statistics, fp32 accumulation and the fp32 classifier head this build
+    keeps.  Those cases carry "outside_north_star_tolerance" in their test ids and are held to a regression bound of
+    1e-2, which is NOT a parity claim.
 """
 import glob
 import os
@@ -22,8 +25,11 @@ import vh_synth as S
 pytestmark = pytest.mark.gpu
 
 vithip = pytest.importorskip("vithip")
-TOL = {vithip.DTYPE_FP16: 1e-3, vithip.DTYPE_BF16: 1e-2}
+NORTH_STAR = 1e-3
+TOL = {vithip.DTYPE_FP16: NORTH_STAR, vithip.DTYPE_BF16: 1e-2}   # bf16: regression bound only, see the module docstring
 NAME = {vithip.DTYPE_FP16: "fp16", vithip.DTYPE_BF16: "bf16"}
+DT_PARAMS = [pytest.param(vithip.DTYPE_FP16, id="fp16-north_star_1e-3"),
+             pytest.param(vithip.DTYPE_BF16, id="bf16-outside_north_star_tolerance-bound_1e-2")]
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -31,7 +37,7 @@ def rel(got, ref):
     return float(np.abs(got - ref).max() / np.abs(ref).max())
 
 
-@pytest.mark.parametrize("dt", [vithip.DTYPE_FP16, vithip.DTYPE_BF16])
+@pytest.mark.parametrize("dt", DT_PARAMS)
 @pytest.mark.parametrize("name,batch", [("vit_micro", 5), ("vit_mini", 3), ("vit_tiny", 3), ("vit_base", 2), ("vit_gray", 7)])
 def test_logits_match_oracle(dt, name, batch):
     cfg = S.CONFIGS[name]
@@ -62,11 +68,71 @@ def test_vit_large_384_long_sequence_config():
     got = ctx.forward(images)
     e = rel(got, ref)
     print(f"\n[parity] vit_large_384 b1 fp16: logits {e:.3e}")
-    assert np.isfinite(got).all() and e <= 1.5e-3, e   # 24 layers: measured slightly above the 12-layer nets
+    assert np.isfinite(got).all() and e <= NORTH_STAR, e
     ctx.close()
 
 
-@pytest.mark.parametrize("dt", [vithip.DTYPE_FP16, vithip.DTYPE_BF16])
+@pytest.mark.parametrize("flags,label", [(vithip.FLAG_LN_FOLD_ON, "folded"), (vithip.FLAG_LN_FOLD_OFF, "stand-alone")])
+def test_fp16_is_inside_the_north_star_tolerance_on_32_vit_b_images(flags, label):
+    """The configuration that carries the parity claim: ViT-B/16, fp16 operands, 32 images, BOTH LayerNorm paths; the worst
+    image must be inside 1e-3 (not the mean, not a sample of two)."""
+    cfg = S.CONFIGS["vit_base"]
+    n = 32
+    blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, n)
+    ref = O.vit_forward(cfg, blob, images)
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=n, flags=flags)
+    ctx.load_weights(blob)
+    assert ctx.ln_fold() == (flags == vithip.FLAG_LN_FOLD_ON)
+    got = ctx.forward(images)
+    ctx.close()
+    per = np.abs(got - ref).max(1) / np.abs(ref).max()
+    print(f"\n[parity] vit_base fp16 {n} images, LayerNorm {label}: worst {per.max():.3e} median {np.median(per):.3e}")
+    assert per.max() <= NORTH_STAR, per.max()
+
+
+def test_layernorm_fold_is_a_property_of_the_configuration_not_of_the_workspace_size():
+    """The same image gives the same logit BITS from a context sized for 1 image and from one sized for 300 (the fold used
+    to switch on with max_batch, so the numerics depended on how the workspace had been sized)."""
+    cfg = S.CONFIGS["vit_base"]
+    blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, 1)
+    outs = []
+    for mb in (1, 300):
+        ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_BF16, max_batch=mb)
+        ctx.load_weights(blob)
+        assert ctx.ln_fold()
+        outs.append(ctx.forward(images))
+        ctx.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_folded_layernorm_with_a_large_common_mode_row_mean():
+    """The folded path multiplies the RAW rounded residual, so its operand rounding error is relative to |x| and not to
+    |x - mean|: it grows like sqrt(1 + (mean/sigma)^2) with a common-mode offset of the rows.  Drive the residual stream
+    with such an offset (position embedding + 1.5 in every channel, |mean| / sigma ~ 5) and check (a) the stand-alone path
+    (VH_FLAG_LN_FOLD_OFF), which normalises in fp32 before rounding, stays inside the north star's tolerance, (b) the folded
+    path degrades by no more than the predicted factor.  This is the documented reason for the flag (include/vithip.h)."""
+    cfg = S.CONFIGS["vit_base"]
+    t = S.make_tensors(cfg, 0)
+    t["pos"] = t["pos"] + np.float32(1.5)
+    blob = S.pack_blob(cfg, t)
+    images = S.make_images(cfg, 1, 4)
+    ref, hid = O.vit_forward(cfg, blob, images, n_layers=0, want_hidden=True)
+    ratio = float(np.abs(hid.mean(1)).mean() / hid.std(1).mean())
+    ref = O.vit_forward(cfg, blob, images)
+    err = {}
+    for flags in (vithip.FLAG_LN_FOLD_OFF, vithip.FLAG_LN_FOLD_ON):
+        ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=4, flags=flags)
+        ctx.load_weights(blob)
+        err[flags] = rel(ctx.forward(images), ref)
+        ctx.close()
+    print(f"\n[fold] |row mean| / sigma at the input of layer 0 = {ratio:.1f}: stand-alone {err[vithip.FLAG_LN_FOLD_OFF]:.3e}, "
+          f"folded {err[vithip.FLAG_LN_FOLD_ON]:.3e}")
+    assert ratio > 3.0
+    assert err[vithip.FLAG_LN_FOLD_OFF] <= NORTH_STAR
+    assert err[vithip.FLAG_LN_FOLD_ON] <= 1.5 * NORTH_STAR * np.sqrt(1.0 + ratio * ratio)
+
+
+@pytest.mark.parametrize("dt", DT_PARAMS)
 def test_logits_match_golden_fixtures(dt):
     for path in sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))):
         g = np.load(path)
@@ -82,25 +148,25 @@ def test_logits_match_golden_fixtures(dt):
         ctx.close()
 
 
-def test_folded_layernorm_path_agrees_with_the_separate_layernorm_path(monkeypatch):
-    # ViT-B (dim % 256 == 0) runs with LayerNorm folded into the q|k|v and fc1 GEMMs; VH_LN_FOLD=0 selects the
+def test_folded_layernorm_path_agrees_with_the_separate_layernorm_path():
+    # ViT-B (dim % 256 == 0) runs with LayerNorm folded into the q|k|v and fc1 GEMMs; VH_FLAG_LN_FOLD_OFF selects the
     # stand-alone LayerNorm kernel.  Both must sit within tolerance of the oracle and close to each other.
     cfg = S.CONFIGS["vit_base"]
     blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, 2)
     ref = O.vit_forward(cfg, blob, images)
     outs = {}
-    for fold in ("1", "0"):
-        monkeypatch.setenv("VH_LN_FOLD", fold)
-        ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=2)
+    for fold in (vithip.FLAG_LN_FOLD_ON, vithip.FLAG_LN_FOLD_OFF):
+        ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=2, flags=fold)
         ctx.load_weights(blob)
         outs[fold] = ctx.forward(images)
         ctx.set_streams(2)                                   # concurrent parts slice the statistics buffers
         assert ctx.get_streams() == 2 and np.array_equal(ctx.forward(images), outs[fold]), fold
         ctx.close()
-        assert rel(outs[fold], ref) <= 1e-3, (fold, rel(outs[fold], ref))
-    print(f"\n[fold] fp16 folded vs separate LN: {rel(outs['1'], outs['0']):.3e}")
-    assert not np.array_equal(outs["1"], outs["0"])   # they really are different code paths
-    assert rel(outs["1"], outs["0"]) <= 1e-3
+        assert rel(outs[fold], ref) <= NORTH_STAR, (fold, rel(outs[fold], ref))
+    a, b = outs[vithip.FLAG_LN_FOLD_ON], outs[vithip.FLAG_LN_FOLD_OFF]
+    print(f"\n[fold] fp16 folded vs separate LN: {rel(a, b):.3e}")
+    assert not np.array_equal(a, b)   # they really are different code paths
+    assert rel(a, b) <= NORTH_STAR
 
 
 def test_layer_by_layer_against_oracle():

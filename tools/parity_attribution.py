@@ -29,13 +29,17 @@ def main():
     ref = O.vit_forward(cfg, blob, images)
     dt = 0 if args.dtype == "bf16" else 1
     B = O.EMUL_BITS
-    plain = B["weights"] | B["ln_out"] | B["qkv"] | B["probs"] | B["attn_out"] | B["gelu_out"] | B["patches"] | B["cls_rows"]
+    plain = (B["weights"] | B["ln_out"] | B["qkv"] | B["probs"] | B["attn_out"] | B["gelu_out"] | B["patches"] | B["cls_rows"]
+             | B["head_weights"])
+    head = B["cls_rows"] | B["head_weights"]
     rows = [(k, v) for k, v in B.items() if k != "ln_folded"]
     rows += [("ln_folded (operand = raw residual)", B["ln_folded"]),
              ("ALL, stand-alone LayerNorm", plain),
-             ("ALL, LayerNorm folded", (plain & ~B["ln_out"]) | B["ln_folded"])]
+             ("ALL, LayerNorm folded", (plain & ~B["ln_out"]) | B["ln_folded"]),
+             ("ALL but the head (fp32 head), stand-alone LN", plain & ~head),
+             ("ALL but the head (fp32 head), LN folded", ((plain & ~B["ln_out"]) | B["ln_folded"]) & ~head)]
     print(f"# {args.config}, {args.images} images (seed {args.seed}), {args.dtype}: max|d|/max|ref| per image vs the fp32 oracle")
-    print(f"{'rounding point':40s} {'worst':>10s} {'median':>10s} {'median^2 share':>15s}")
+    print(f"{'rounding point':48s} {'worst':>10s} {'median':>10s} {'median^2 share':>15s}")
     res = []
     for name, mask in rows:
         got = O.vit_forward_emul16(cfg, blob, images, dt, mask)
@@ -44,7 +48,7 @@ def main():
     tot = sum(m * m for n, w, m in res if not n.startswith("ALL") and not n.startswith("ln_folded"))
     for name, w, m in res:
         share = f"{100 * m * m / tot:14.1f}%" if not name.startswith("ALL") else ""
-        print(f"{name:40s} {w:10.3e} {m:10.3e} {share:>15s}")
+        print(f"{name:48s} {w:10.3e} {m:10.3e} {share:>15s}")
 
 
 if __name__ == "__main__":

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Parity statistics on a larger sample than the unit tests use: ViT-B/16, 64 images, against the CPU oracle.
-Context created with max_batch 512 so that the default (folded LayerNorm) path of the benchmark is the one measured;
-VH_LN_FOLD=0 measures the stand-alone path."""
+PARITY_FOLD=on|off selects the LayerNorm path through vh_config.flags (default: the library's, folded for ViT-B)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-fpga_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,11 +8,13 @@ import numpy as np, oracle_lib as O, vh_synth as S, vithip
 cfg = S.CONFIGS["vit_base"]; n = 64
 blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, n)
 ref = O.vit_forward(cfg, blob, images)
+fold = os.environ.get("PARITY_FOLD", "default")
+flags = {"on": vithip.FLAG_LN_FOLD_ON, "off": vithip.FLAG_LN_FOLD_OFF}.get(fold, 0)
 for name, dt in (("fp16", vithip.DTYPE_FP16), ("bf16", vithip.DTYPE_BF16), ("fp8", vithip.DTYPE_FP8)):
-    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=512); ctx.load_weights(blob); got = ctx.forward(images); ctx.close()
+    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=n, flags=flags); ctx.load_weights(blob); got = ctx.forward(images); ctx.close()
     per = np.abs(got - ref).max(1) / np.abs(ref).max()
     rms = np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2))
     top1 = (got.argmax(1) == ref.argmax(1)).mean()
     top5 = np.mean([len(set(np.argsort(-got[i])[:5]) & set(np.argsort(-ref[i])[:5])) / 5 for i in range(n)])
-    print(f"vit_base {n} images {name} fold={os.environ.get('VH_LN_FOLD', 'auto')}: max|d|/max|ref| worst {per.max():.3e} median {np.median(per):.3e}; "
+    print(f"vit_base {n} images {name} LayerNorm fold={fold}: max|d|/max|ref| worst {per.max():.3e} median {np.median(per):.3e}; "
           f"rms {rms:.3e}; top-1 agreement {top1:.3f}, top-5 overlap {top5:.3f}")

@@ -70,6 +70,7 @@ static hipError_t ln_t(const float* x, int64_t rows, int dim, int64_t stride, co
 hipError_t launch_layernorm(const float* x, int64_t rows, int dim, int64_t row_stride, const float* gamma,
                             const float* beta, float eps, void* out16, int dtype, hipStream_t s) {
     if (rows <= 0 || dim <= 0 || (dim & 3) || (row_stride & 3)) return hipErrorInvalidValue;
+    if (dtype == VH_DTYPE_F32_INTERNAL) return ln_t<F32OUT>(x, rows, dim, row_stride, gamma, beta, eps, out16, s);
     if (dtype == VH_DTYPE_FP8) return ln_t<E4M3>(x, rows, dim, row_stride, gamma, beta, eps, out16, s);  // 1 byte / element
     return dtype == VH_DTYPE_BF16 ? ln_t<BF16>(x, rows, dim, row_stride, gamma, beta, eps, out16, s)
                                   : ln_t<FP16>(x, rows, dim, row_stride, gamma, beta, eps, out16, s);
@@ -450,6 +451,70 @@ hipError_t launch_filter3x3(const uint8_t* in, uint8_t* out, int h, int w, int k
     const dim3 grid((unsigned)((w + 1023) / 1024), (unsigned)h), block(256);
     if (kind == 0) hipLaunchKernelGGL(filter3x3_kernel<0>, grid, block, 0, s, in, out, h, w);
     else hipLaunchKernelGGL(filter3x3_kernel<1>, grid, block, 0, s, in, out, h, w);
+    return hipGetLastError();
+}
+
+// ---- classifier head in fp32 --------------------------------------------------------------------------------------
+//   logits[b, c] = sum_k y[b, k] * W[c, k] + bias[c]        y = final-LayerNorm'd CLS rows (fp32), W / bias = the canonical
+// fp32 tensors of the blob, read in place.
+// The head is 0.002 % of a forward's FLOPs but the LAST rounding point in front of the logits: with 16-bit operands its
+// two roundings (CLS rows, head weights) alone were 7 % + of the logit error variance (tools/parity_attribution.py).
+// v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain (k-ordered), so this GEMM adds no operand rounding at all.
+// One wave = 16 images x 64 classes: the W rows are the MFMA "A" operand, so a lane ends up with 4 consecutive classes of
+// one image (one 16-byte store).  A lane's float4 load covers k = kb + 4 (lane >> 4) + {0..3}; element j of the A and of
+// the B load go into MFMA j of the group, so both operands see the same k: the 4 x 4 (lane group, j) pairs cover
+// kb .. kb + 15 exactly once.
+__global__ void __launch_bounds__(256)
+head_f32_kernel(const float* __restrict__ y, const float* __restrict__ w, const float* __restrict__ bias,
+                float* __restrict__ out, int batch, int classes, int dim, int ncg) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int bb = gw / ncg, cg = gw - bb * ncg;
+    if (bb * 16 >= batch) return;
+    const int r = lane & 15, g = lane >> 4;
+    int b = bb * 16 + r;
+    b = b < batch ? b : batch - 1;
+    const float* yp = y + (int64_t)b * dim + 4 * g;
+    const float* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = cg * 64 + i * 16 + r;
+        c = c < classes ? c : classes - 1;
+        wp[i] = w + (int64_t)c * dim + 4 * g;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < dim; kb += 16) {
+        const f32x4 yv = *(const f32x4*)(yp + kb);
+        f32x4 wv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[i] = *(const f32x4*)(wp[i] + kb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][j], yv[j], acc[i], 0, 0, 0);
+    }
+    // D[row = class (lane >> 4) * 4 + reg][col = image lane & 15]
+    const int bo = bb * 16 + r;
+    if (bo < batch) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cg * 64 + i * 16 + 4 * g;
+            if (c < classes) {   // classes % 4 == 0: a quad is inside or outside as a whole
+                const f32x4 bv = *(const f32x4*)(bias + c);
+                *(f32x4*)(out + (int64_t)bo * classes + c) = acc[i] + bv;
+            }
+        }
+    }
+}
+
+hipError_t launch_head_f32(const float* y, const float* w, const float* bias, float* out, int batch, int classes, int dim,
+                           hipStream_t s) {
+    if (batch <= 0 || classes <= 0 || (classes & 3) || dim <= 0 || (dim & 15)) return hipErrorInvalidValue;
+    const int ncg = (classes + 63) / 64, nb = (batch + 15) / 16;
+    const int waves = ncg * nb;
+    hipLaunchKernelGGL(head_f32_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, y, w, bias, out, batch, classes, dim, ncg);
     return hipGetLastError();
 }
 

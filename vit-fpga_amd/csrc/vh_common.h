@@ -53,6 +53,12 @@ struct FP16 {
     }
 };
 
+// fp32 "output type" of the kernels templated on their result element (final LayerNorm of the CLS rows -> fp32 head)
+struct F32OUT {
+    using elem = float;
+    using vec4 = f32x4;
+};
+
 template <typename T>
 __device__ __forceinline__ typename T::vec4 pack4(float a, float b, float c, float d) {
     typename T::vec4 v;
@@ -85,6 +91,10 @@ __device__ __forceinline__ uint32_t pack4_e4m3(float a, float b, float c, float 
 template <>
 __device__ __forceinline__ uint32_t pack4<E4M3>(float a, float b, float c, float d) {
     return pack4_e4m3(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ f32x4 pack4<F32OUT>(float a, float b, float c, float d) {
+    return f32x4{a, b, c, d};
 }
 
 __device__ __forceinline__ float gelu_erf(float v) {

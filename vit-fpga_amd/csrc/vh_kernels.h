@@ -38,6 +38,11 @@ int gemm_pp_variant(int epilogue);  // 5, 6 or 7 (default: 6 for 16-bit results,
 hipError_t launch_layernorm(const float* x, int64_t rows, int dim, int64_t row_stride,
                             const float* gamma, const float* beta, float eps, void* out16,
                             int dtype, hipStream_t stream);
+// dtype = VH_DTYPE_* (16-bit / e4m3 result) or VH_DTYPE_F32_INTERNAL (fp32 result: the final LayerNorm in front of the head)
+constexpr int VH_DTYPE_F32_INTERNAL = 100;
+// classifier head, fp32 operands (exact-fp32 MFMA): logits[b, c] = y[b, :] . w[c, :] + bias[c]; classes % 4 == 0, dim % 16 == 0
+hipError_t launch_head_f32(const float* y, const float* w, const float* bias, float* out, int batch, int classes, int dim,
+                           hipStream_t stream);
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16,
                             int dtype, hipStream_t stream);
 size_t attention_lds_bytes(int tokens);

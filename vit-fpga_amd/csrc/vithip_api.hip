@@ -7,12 +7,19 @@
 // (/root/reference/src/netFPGA.cpp:239-290, 367-515, 639-651) — see the per-function notes in
 // the header.  No CPU fallback exists: without a gfx950 device every compute entry point
 // fails with VH_ERR_NO_DEVICE / VH_ERR_HIP.
+#include <dlfcn.h>
+
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "vh_kernels.h"
@@ -92,6 +99,14 @@ Layout make_layout(const vh_config& c) {
     return L;
 }
 
+// expected blob size of a configuration computed WITHOUT building the layout (no allocation): used on untrusted headers
+size_t blob_bytes_of(const vh_config& c) {
+    const size_t D = c.dim, M = c.mlp_dim, C = c.classes, g = (size_t)(c.image_size / c.patch_size);
+    const size_t T = g * g + 1, KP = (size_t)c.patch_size * c.patch_size * c.channels;
+    const size_t per_layer = 2 * D + 4 * (D * D + D) + 2 * D + (M * D + M) + (D * M + D);
+    return sizeof(BlobHeader) + 4 * (D * KP + D + D + T * D + (size_t)c.layers * per_layer + 2 * D + C * D + C);
+}
+
 const char* check_config(const vh_config& c) {
     if (c.image_size <= 0 || c.patch_size <= 0 || c.image_size % c.patch_size) return "image_size must be a positive multiple of patch_size";
     if (c.channels <= 0 || (c.patch_size * c.channels) % 4) return "patch_size*channels must be a multiple of 4";
@@ -106,7 +121,12 @@ const char* check_config(const vh_config& c) {
     if (c.dtype == VH_DTYPE_FP8 && (c.dim % 128 || c.mlp_dim % 128)) return "VH_DTYPE_FP8 needs dim and mlp_dim to be multiples of 128";
     if (c.max_batch <= 0) return "max_batch must be positive";
     if (!(c.ln_eps > 0.f)) return "ln_eps must be positive";
-    if (c.reserved != 0) return "reserved must be 0";
+    if (c.flags & ~(VH_FLAG_LN_FOLD_OFF | VH_FLAG_LN_FOLD_ON)) return "unknown bits in flags";
+    if ((c.flags & VH_FLAG_LN_FOLD_OFF) && (c.flags & VH_FLAG_LN_FOLD_ON)) return "flags: VH_FLAG_LN_FOLD_OFF and VH_FLAG_LN_FOLD_ON exclude each other";
+    // bounds that keep every size computation below far from overflow (and a crafted file header from driving an
+    // allocation: vh_blob_file_config feeds this function)
+    if (c.image_size > 4096 || c.patch_size > 256 || c.channels > 64) return "image_size <= 4096, patch_size <= 256, channels <= 64";
+    if (c.layers > 4096 || c.classes > (1 << 20) || c.mlp_dim > (1 << 16) || c.max_batch > (1 << 20)) return "layers <= 4096, classes <= 2^20, mlp_dim <= 2^16, max_batch <= 2^20";
     const int g = c.image_size / c.patch_size;
     if (attention_lds_bytes(g * g + 1) > 160 * 1024) return "token count too large for the LDS-resident attention kernel";
     return nullptr;
@@ -136,7 +156,6 @@ struct vh_ctx {
     float* params = nullptr;  // blob + 64
     char* w16 = nullptr;      // arena of 16-bit matrices
     void* wp16 = nullptr;     // [D, KP]
-    void* head16 = nullptr;   // [C, D]
     std::vector<void*> wqkv16, wo16, w1_16, w2_16;
     float* bqkv = nullptr;    // [layers, 3D]
     // VH_DTYPE_FP8: the four per-layer matrices hold e4m3 bytes (in the same arena) + one fp32 scale per output channel;
@@ -157,7 +176,7 @@ struct vh_ctx {
     void* att16 = nullptr;    //                 [B*T, D]
     void* h16 = nullptr;      //                 [B*T, M]
     void* col16 = nullptr;    // patch matrix    [B*NP, KP]
-    void* clsn16 = nullptr;   // final-LN'd CLS  [B, D]
+    float* clsn32 = nullptr;  // final-LN'd CLS  [B, D] fp32 (the head runs in fp32 on the blob's own weights)
     float* in_dev = nullptr;  // staging for the host-pointer forward
     float* logits_dev = nullptr;
     int64_t last_us = 0;
@@ -270,7 +289,6 @@ int prepare_weights(vh_ctx* c) {
         HIPCHK(&c->err, launch_cast(P + o.ow, c->wo16[l], (int64_t)D * D, f.dtype, s));
         HIPCHK(&c->err, launch_cast(P + o.f2w, c->w2_16[l], (int64_t)D * M, f.dtype, s));
     }
-    HIPCHK(&c->err, launch_cast(P + L.headw, c->head16, (int64_t)f.classes * D, c->dt16, s));
     HIPCHK(&c->err, hipStreamSynchronize(s));
     c->weights_ready = true;
     return VH_OK;
@@ -308,7 +326,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     char* const att16 = (char*)c->att16 + r0 * D * esz_op;
     char* const h16 = (char*)c->h16 + r0 * M * esz_op;
     char* const col16 = (char*)c->col16 + (size_t)img0 * L.NP * L.KP * esz;
-    char* const clsn16 = (char*)c->clsn16 + (size_t)img0 * D * esz;
+    float* const clsn32 = c->clsn32 + (size_t)img0 * D;
     auto mark = [&](int stage) -> int {
         if (!ev) return VH_OK;
         hipEvent_t e;
@@ -460,9 +478,9 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = resid_gemm_ln(h16, c->w2_16[l], P + o.f2b, s2, M, more ? P + L.layer[l + 1].ln1w : nullptr,
                                 more ? P + L.layer[l + 1].ln1b : nullptr, ST_FC2))) return rc;
     }
-    HIPCHK(&c->err, launch_layernorm(x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn16, dt16, s));
+    HIPCHK(&c->err, launch_layernorm(x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn32, VH_DTYPE_F32_INTERNAL, s));
     if ((rc = mark(ST_LNF))) return rc;
-    HIPCHK(&c->err, gemm(clsn16, c->head16, P + L.headb, logits, batch, f.classes, D, VH_EPI_BIAS_F32, nullptr, 0));
+    HIPCHK(&c->err, launch_head_f32(clsn32, P + L.headw, P + L.headb, logits, batch, f.classes, D, s));
     if ((rc = mark(ST_HEAD))) return rc;
     c->last_batch = batch;
     return VH_OK;
@@ -606,7 +624,7 @@ int vh_device_synchronize(int device) {
 
 size_t vh_weight_blob_bytes(const vh_config* cfg) {
     if (!cfg || check_config(*cfg)) return 0;
-    return sizeof(BlobHeader) + 4 * make_layout(*cfg).total;
+    return blob_bytes_of(*cfg);
 }
 
 int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
@@ -620,10 +638,16 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, VH_ERR_NO_DEVICE, "device %d is %s; libvithip is built for gfx950 only", device, prop.gcnArchName);
 
-    vh_ctx* c = new vh_ctx();
-    c->cfg = *cfg;
+    vh_ctx* c = nullptr;
+    try {
+        c = new vh_ctx();
+        c->cfg = *cfg;
+        c->L = make_layout(*cfg);
+    } catch (const std::exception& ex) {   // nothing may leave an extern "C" entry point as a C++ exception
+        delete c;
+        return fail(nullptr, VH_ERR_INVALID, "vh_create: %s", ex.what());
+    }
     c->device = device;
-    c->L = make_layout(*cfg);
     const Layout& L = c->L;
     const size_t D = cfg->dim, M = cfg->mlp_dim, C = cfg->classes, B = cfg->max_batch;
     const size_t rows = B * (size_t)L.T;
@@ -663,21 +687,22 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     // 16-bit weights
     size_t w16_bytes = 0;
     auto carve16 = [&](size_t elems) { size_t o = w16_bytes; w16_bytes += align_up(elems * 2, 256); return o; };
-    const size_t o_wp = carve16(D * L.KP), o_head = carve16(C * D);
+    const size_t o_wp = carve16(D * L.KP);
     std::vector<size_t> o_qkv(cfg->layers), o_o(cfg->layers), o_1(cfg->layers), o_2(cfg->layers);
     for (int l = 0; l < cfg->layers; ++l) { o_qkv[l] = carve16(3 * D * D); o_o[l] = carve16(D * D); o_1[l] = carve16(M * D); o_2[l] = carve16(D * M); }
     const size_t o_bqkv = w16_bytes;
     w16_bytes += align_up((size_t)cfg->layers * 3 * D * 4, 256);
     {
-        const char* e = getenv("VH_LN_FOLD");
-        // LayerNorm folded into the neighbouring GEMMs.  VH_LN_FOLD=1 / 0 force it on (where the shapes allow) / off;
-        // unset: on for large workloads (>= 50 000 token rows at max_batch).  ViT-B/16 b512: the 24 LayerNorm launches
-        // (1.99 ms at the HBM roofline, 11 GB of the forward's traffic) disappear, the RESID_LN / LNFOLD epilogues and
-        // the 24 statistics kernels cost 1.1 ms: +1.0 ... +4.4 % images/s depending on the box (boxes differ in how hard
-        // the power cap bites); at batch 64-256 it is -0.3 ... -1.2 %, hence the threshold.
+        // LayerNorm folded into the neighbouring GEMMs: a property of the MODEL SHAPE and of vh_config.flags only -- never of
+        // max_batch, so that a context sized for 1 image and one sized for 512 give the same logit bits for the same image
+        // (and hip::net_hip, which re-creates its context when a larger batch arrives, keeps its numerics).  On by default
+        // where the shapes allow it.  VH_LN_FOLD=0 / 1 (environment, A/B tools) applies only when the flags leave the choice
+        // to the library.
         const bool eligible = (cfg->dim % 256 == 0) && (cfg->mlp_dim % 256 == 0);
-        const bool large = (size_t)cfg->max_batch * (size_t)L.T >= 50000;
-        c->ln_fold = eligible && (e ? e[0] == '1' : large);
+        bool want = true;
+        if (cfg->flags & VH_FLAG_LN_FOLD_OFF) want = false;
+        else if (!(cfg->flags & VH_FLAG_LN_FOLD_ON)) { const char* e = getenv("VH_LN_FOLD"); if (e) want = e[0] == '1'; }
+        c->ln_fold = eligible && want;
     }
     c->fp8 = cfg->dtype == VH_DTYPE_FP8;
     c->dt16 = c->fp8 ? VH_DTYPE_BF16 : cfg->dtype;
@@ -687,7 +712,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     const size_t o_sc = w16_bytes, sc_per_layer = 5 * D + M;  // fp8: scales of q|k|v (3D), o (D), fc1 (M), fc2 (D)
     if (c->fp8) w16_bytes += align_up((size_t)cfg->layers * sc_per_layer * 4, 256);
     CK(hipMalloc((void**)&c->w16, w16_bytes));
-    c->wp16 = c->w16 + o_wp; c->head16 = c->w16 + o_head; c->bqkv = (float*)(c->w16 + o_bqkv);
+    c->wp16 = c->w16 + o_wp; c->bqkv = (float*)(c->w16 + o_bqkv);
     c->fold_cd = (float*)(c->w16 + o_cd);
     for (int l = 0; l < cfg->layers; ++l) {
         c->wqkv16.push_back(c->w16 + o_qkv[l]); c->wo16.push_back(c->w16 + o_o[l]);
@@ -702,12 +727,12 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     auto carve = [&](size_t bytes) { size_t o = a; a += align_up(bytes, 256); return o; };
     const size_t o_x = carve(rows * D * 4), o_xn = carve(rows * D * 2), o_qkvA = carve(rows * 3 * D * 2),
                  o_att = carve(rows * D * 2), o_h = carve(rows * M * 2), o_col = carve(B * L.NP * (size_t)L.KP * 2),
-                 o_cls = carve(B * D * 2),
+                 o_cls = carve(B * D * 4),
                  o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4),
                  o_st = carve(rows * 2 * 4), o_pt = carve((D / 64 + 1) * rows * 2 * 4);
     CK(hipMalloc((void**)&c->arena, a));
     c->x = (float*)(c->arena + o_x); c->xn16 = c->arena + o_xn; c->qkv16 = c->arena + o_qkvA; c->att16 = c->arena + o_att;
-    c->h16 = c->arena + o_h; c->col16 = c->arena + o_col; c->clsn16 = c->arena + o_cls;
+    c->h16 = c->arena + o_h; c->col16 = c->arena + o_col; c->clsn32 = (float*)(c->arena + o_cls);
     c->in_dev = (float*)(c->arena + o_in); c->logits_dev = (float*)(c->arena + o_lg);
     c->stats = (float*)(c->arena + o_st); c->partials = (float*)(c->arena + o_pt);
 #undef CK
@@ -743,6 +768,12 @@ int vh_destroy(vh_ctx* c) {
 int vh_get_config(const vh_ctx* c, vh_config* out) {
     if (!c || !out) return fail(nullptr, VH_ERR_INVALID, "null argument");
     *out = c->cfg;
+    return VH_OK;
+}
+
+int vh_get_ln_fold(const vh_ctx* c, int* on) {
+    if (!c || !on) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *on = c->ln_fold ? 1 : 0;
     return VH_OK;
 }
 
@@ -827,8 +858,7 @@ int vh_export_weights(vh_ctx* c, void* host_blob, size_t nbytes) {
 // The file IS the canonical blob (64-byte header + fp32 tensors in the fixed order of make_layout), with a
 // checksum of the parameter bytes in the header words a memory blob leaves zero.  It is what vh_load_weights
 // takes, what vh_export_weights returns and what the multi-GPU path broadcasts.
-int vh_blob_file_config(const char* path, vh_config* cfg) {
-    if (!path || !cfg) return fail(nullptr, VH_ERR_INVALID, "null argument");
+static int blob_file_header(const char* path, vh_config* cfg, size_t* need_out) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(nullptr, VH_ERR_INVALID, "cannot open %s", path);
     BlobHeader h;
@@ -842,10 +872,42 @@ int vh_blob_file_config(const char* path, vh_config* cfg) {
     c.image_size = h.image_size; c.patch_size = h.patch_size; c.channels = h.channels; c.dim = h.dim; c.heads = h.heads;
     c.mlp_dim = h.mlp_dim; c.layers = h.layers; c.classes = h.classes; c.ln_eps = h.ln_eps;
     c.dtype = VH_DTYPE_BF16; c.max_batch = 1;
+    // check_config bounds every field, so the size arithmetic below cannot overflow and nothing is allocated from the header
     if (const char* why = check_config(c)) return fail(nullptr, VH_ERR_INVALID, "%s: header describes an unsupported model (%s)", path, why);
-    const size_t need = sizeof(BlobHeader) + 4 * make_layout(c).total;
+    const size_t need = blob_bytes_of(c);
     if (fsize != (long long)need) return fail(nullptr, VH_ERR_INVALID, "%s: %lld bytes, the header implies %zu", path, fsize, need);
     *cfg = c;
+    if (need_out) *need_out = need;
+    return VH_OK;
+}
+
+int vh_blob_file_config(const char* path, vh_config* cfg) {
+    if (!path || !cfg) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    return blob_file_header(path, cfg, nullptr);
+}
+
+int vh_blob_file_read(const char* path, void* host_blob, size_t nbytes) {
+    if (!path || !host_blob) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    vh_config c;
+    size_t need = 0;
+    int rc = blob_file_header(path, &c, &need);
+    if (rc) return rc;
+    if (nbytes != need) return fail(nullptr, VH_ERR_INVALID, "%s is %zu bytes, the buffer %zu", path, need, nbytes);
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(nullptr, VH_ERR_INVALID, "cannot open %s", path);
+    const size_t got = fread(host_blob, 1, need, f);
+    fclose(f);
+    if (got != need) return fail(nullptr, VH_ERR_INVALID, "%s: short read", path);
+    BlobHeader h;
+    memcpy(&h, host_blob, sizeof h);
+    if (h.flags & 1) {
+        const uint64_t sum = fnv1a64((const char*)host_blob + sizeof h, need - sizeof h);
+        if ((uint32_t)sum != h.sum_lo || (uint32_t)(sum >> 32) != h.sum_hi)
+            return fail(nullptr, VH_ERR_INVALID, "%s: checksum mismatch (file damaged)", path);
+    }
+    h.sum_lo = h.sum_hi = h.flags = 0;   // memory form
+    h.pad[0] = h.pad[1] = 0;
+    memcpy(host_blob, &h, sizeof h);
     return VH_OK;
 }
 
@@ -1187,12 +1249,7 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
     if (what == 1) {
         const size_t n = (size_t)c->last_batch * D;
         if (n_floats != n) return fail(&c->err, VH_ERR_INVALID, "expected %zu floats", n);
-        std::vector<uint16_t> tmp(n);
-        HIPCHK(&c->err, hipMemcpy(tmp.data(), c->clsn16, n * 2, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) {
-            if (c->dt16 == VH_DTYPE_BF16) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&host_out[i], &u, 4); }
-            else { _Float16 hval; memcpy(&hval, &tmp[i], 2); host_out[i] = (float)hval; }
-        }
+        HIPCHK(&c->err, hipMemcpy(host_out, c->clsn32, n * 4, hipMemcpyDeviceToHost));
         return VH_OK;
     }
     return fail(&c->err, VH_ERR_INVALID, "unknown tap %d", what);
@@ -1535,6 +1592,288 @@ int vh_mlp_destroy(vh_mlp* m) {
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
     return VH_OK;
+}
+
+}  // extern "C"
+
+// ---- device group: N GPUs of one node from ONE process ---------------------------------------------
+// The reference drives exactly one device (clGetDeviceIDs(ACCELERATOR), netFPGA.cpp:376) with one input per call
+// (:266-277); nothing to mirror, so the contract is the survey's: single process, one host thread + one context (own
+// stream) per device, ncclCommInitAll, ONE ncclBroadcast of the canonical weight blob (what _load_params uploads per
+// device, netFPGA.cpp:484-515) from member 0, contiguous image ranges per member, per-member D2H straight into the
+// caller's logits; no collective on the data path.  RCCL is bound at run time (dlopen) and only when a group has more
+// than one distinct device, so libvithip.so itself carries no RCCL dependency.
+struct vh_group {
+    struct Member {
+        int device = 0;
+        vh_ctx* ctx = nullptr;
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int()> job;   // pending command (empty = none)
+        bool quit = false, busy = false;
+        int rc = VH_OK;
+        float *in_dev = nullptr, *out_dev = nullptr;   // device-resident benchmark buffers
+        int resident_batch = 0;
+    };
+    vh_config cfg;
+    std::vector<std::unique_ptr<Member>> m;
+    bool same_device = false;   // rehearsal: duplicate ordinals, broadcast by D2D copy instead of RCCL
+    void* rccl = nullptr;       // dlopen handle
+    std::vector<void*> comms;   // ncclComm_t per member
+    std::string err;
+};
+
+namespace {
+
+struct RcclApi {
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+int bind_rccl(vh_group* g) {
+    if (g->rccl) return VH_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { g->rccl = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g->rccl) break; }
+    if (!g->rccl) return fail(&g->err, VH_ERR_UNSUPPORTED, "vh_group: cannot load librccl.so (%s)", dlerror());
+    auto sym = [&](const char* n) { return dlsym(g->rccl, n); };
+    g_rccl.CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
+    g_rccl.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+    g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclBroadcast");
+    g_rccl.GroupStart = (int (*)())sym("ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    g_rccl.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.Broadcast || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.GetErrorString)
+        return fail(&g->err, VH_ERR_UNSUPPORTED, "vh_group: librccl.so lacks a required symbol");
+    return VH_OK;
+}
+
+void member_loop(vh_group::Member* m) {
+    hipSetDevice(m->device);
+    std::unique_lock<std::mutex> lk(m->mu);
+    for (;;) {
+        m->cv.wait(lk, [&] { return m->quit || (bool)m->job; });
+        if (m->quit) return;
+        std::function<int()> job = std::move(m->job);
+        m->job = nullptr;
+        lk.unlock();
+        const int rc = job();
+        lk.lock();
+        m->rc = rc;
+        m->busy = false;
+        m->cv.notify_all();
+    }
+}
+
+// run one command per member concurrently, wait for all; returns the first failure
+int run_all(vh_group* g, const std::function<int(int)>& cmd) {
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        vh_group::Member* m = g->m[i].get();
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->busy = true;
+        m->job = [cmd, i]() { return cmd((int)i); };
+        m->cv.notify_all();
+    }
+    int rc = VH_OK;
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        vh_group::Member* m = g->m[i].get();
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->cv.wait(lk, [&] { return !m->busy; });
+        if (m->rc != VH_OK && rc == VH_OK) {
+            rc = m->rc;
+            g->err = std::string("member ") + std::to_string(i) + " (device " + std::to_string(m->device) + "): " + m->ctx->err;
+        }
+    }
+    if (rc != VH_OK) g_err = g->err;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vh_group_shard_bounds(int batch, int n, int r, int* lo, int* hi) {
+    // contiguous image range of member r; the first (batch % n) members take one extra image
+    const int base = batch / n, extra = batch % n;
+    const int l = r * base + (r < extra ? r : extra);
+    if (lo) *lo = l;
+    if (hi) *hi = l + base + (r < extra ? 1 : 0);
+}
+
+const char* vh_group_last_error(const vh_group* g) { return g ? g->err.c_str() : g_err.c_str(); }
+
+int vh_group_destroy(vh_group* g) {
+    if (!g) return VH_OK;
+    for (auto& mp : g->m) {
+        vh_group::Member* m = mp.get();
+        if (m->th.joinable()) {
+            { std::lock_guard<std::mutex> lk(m->mu); m->quit = true; m->cv.notify_all(); }
+            m->th.join();
+        }
+    }
+    for (size_t i = 0; i < g->comms.size(); ++i)
+        if (g->comms[i] && g_rccl.CommDestroy) { hipSetDevice(g->m[i]->device); g_rccl.CommDestroy(g->comms[i]); }
+    for (auto& mp : g->m) {
+        hipSetDevice(mp->device);
+        if (mp->in_dev) hipFree(mp->in_dev);
+        if (mp->out_dev) hipFree(mp->out_dev);
+        if (mp->ctx) vh_destroy(mp->ctx);
+    }
+    delete g;
+    return VH_OK;
+}
+
+int vh_group_create(const vh_config* cfg, const int* devices, int n, vh_group** out) {
+    if (!cfg || !devices || !out || n < 1 || n > 64) return fail(nullptr, VH_ERR_INVALID, "vh_group_create: bad argument");
+    *out = nullptr;
+    vh_group* g = new vh_group();
+    g->cfg = *cfg;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) g->same_device |= devices[i] == devices[j];
+    for (int i = 0; i < n; ++i) {
+        std::unique_ptr<vh_group::Member> m(new vh_group::Member());
+        m->device = devices[i];
+        const int rc = vh_create(cfg, devices[i], &m->ctx);
+        g->m.push_back(std::move(m));
+        if (rc != VH_OK) { vh_group_destroy(g); return rc; }
+    }
+    const char* force = getenv("VH_GROUP_FORCE_RCCL");
+    if ((n > 1 && !g->same_device) || (force && force[0] == '1' && !g->same_device)) {
+        int rc = bind_rccl(g);
+        if (rc == VH_OK) {
+            g->comms.assign(n, nullptr);
+            const int r = g_rccl.CommInitAll(g->comms.data(), n, devices);
+            if (r != 0) rc = fail(&g->err, VH_ERR_HIP, "ncclCommInitAll: %s", g_rccl.GetErrorString(r));
+        }
+        if (rc != VH_OK) { const std::string e = g->err; vh_group_destroy(g); g_err = e; return rc; }
+    }
+    for (auto& mp : g->m) mp->th = std::thread(member_loop, mp.get());
+    *out = g;
+    return VH_OK;
+}
+
+int vh_group_size(const vh_group* g, int* n) {
+    if (!g || !n) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *n = (int)g->m.size();
+    return VH_OK;
+}
+
+int vh_group_member(vh_group* g, int i, vh_ctx** ctx, int* device) {
+    if (!g || i < 0 || i >= (int)g->m.size()) return fail(g ? &g->err : nullptr, VH_ERR_INVALID, "vh_group_member: bad index");
+    if (ctx) *ctx = g->m[i]->ctx;
+    if (device) *device = g->m[i]->device;
+    return VH_OK;
+}
+
+// member 0's resident canonical blob -> every other member's blob buffer (one ncclBroadcast over xGMI), then every other
+// member converts it to its compute layout (vh_load_weights_device, the same code path a blob from an RCCL broadcast of
+// the multi-process form takes)
+int vh_group_broadcast_weights(vh_group* g) {
+    if (!g) return fail(nullptr, VH_ERR_INVALID, "null group");
+    vh_ctx* root = g->m[0]->ctx;
+    if (!root->weights_ready) return fail(&g->err, VH_ERR_STATE, "vh_group_broadcast_weights: member 0 has no weights");
+    const size_t nbytes = sizeof(BlobHeader) + 4 * root->L.total;
+    const int n = (int)g->m.size();
+    if (!g->comms.empty()) {
+        HIPCHK(&g->err, hipSetDevice(g->m[0]->device));
+        HIPCHK(&g->err, hipStreamSynchronize(root->stream));
+        int r = g_rccl.GroupStart();
+        for (int i = 0; i < n && r == 0; ++i) {
+            HIPCHK(&g->err, hipSetDevice(g->m[i]->device));
+            vh_ctx* c = g->m[i]->ctx;
+            r = g_rccl.Broadcast(root->blob, c->blob, nbytes, /*ncclUint8*/ 1, 0, g->comms[i], c->stream);
+        }
+        const int r2 = g_rccl.GroupEnd();
+        if (r == 0) r = r2;
+        if (r != 0) return fail(&g->err, VH_ERR_HIP, "ncclBroadcast: %s", g_rccl.GetErrorString(r));
+        for (int i = 0; i < n; ++i) {
+            HIPCHK(&g->err, hipSetDevice(g->m[i]->device));
+            HIPCHK(&g->err, hipStreamSynchronize(g->m[i]->ctx->stream));
+        }
+    } else if (n > 1) {   // rehearsal group on one device: the broadcast is a device-to-device copy
+        HIPCHK(&g->err, hipSetDevice(g->m[0]->device));
+        HIPCHK(&g->err, hipStreamSynchronize(root->stream));
+        for (int i = 1; i < n; ++i) HIPCHK(&g->err, hipMemcpy(g->m[i]->ctx->blob, root->blob, nbytes, hipMemcpyDeviceToDevice));
+    }
+    return run_all(g, [g, nbytes](int i) { return i == 0 ? VH_OK : vh_load_weights_device(g->m[i]->ctx, g->m[i]->ctx->blob, nbytes); });
+}
+
+int vh_group_load_weights(vh_group* g, const void* host_blob, size_t nbytes) {
+    if (!g || !host_blob) return fail(g ? &g->err : nullptr, VH_ERR_INVALID, "null argument");
+    int rc = vh_load_weights(g->m[0]->ctx, host_blob, nbytes);
+    if (rc != VH_OK) { g->err = g->m[0]->ctx->err; return rc; }
+    return vh_group_broadcast_weights(g);
+}
+
+int vh_group_init_weights_seeded(vh_group* g, uint64_t seed) {
+    if (!g) return fail(nullptr, VH_ERR_INVALID, "null group");
+    int rc = vh_init_weights_seeded(g->m[0]->ctx, seed);
+    if (rc != VH_OK) { g->err = g->m[0]->ctx->err; return rc; }
+    return vh_group_broadcast_weights(g);
+}
+
+// The hot path over the group: `batch` images in host memory, member r takes the contiguous range vh_group_shard_bounds
+// gives it and writes its logits straight into the caller's buffer.  Every member runs its vh_forward (H2D, kernels,
+// blocking D2H: the reference's launch_forward window, netFPGA.cpp:262-284) on its own host thread and stream.
+int vh_group_forward(vh_group* g, const float* in_host, int batch, float* logits_host) {
+    if (!g || !in_host || !logits_host) return fail(g ? &g->err : nullptr, VH_ERR_INVALID, "null argument");
+    const int n = (int)g->m.size();
+    if (batch < 1) return fail(&g->err, VH_ERR_INVALID, "batch must be positive");
+    if ((batch + n - 1) / n > g->cfg.max_batch)
+        return fail(&g->err, VH_ERR_INVALID, "batch %d over %d devices exceeds max_batch=%d per device", batch, n, g->cfg.max_batch);
+    const size_t img = (size_t)g->cfg.image_size * g->cfg.image_size * g->cfg.channels, cls = (size_t)g->cfg.classes;
+    return run_all(g, [=](int i) {
+        int lo, hi;
+        vh_group_shard_bounds(batch, n, i, &lo, &hi);
+        if (hi == lo) return VH_OK;   // fewer images than members
+        return vh_forward(g->m[i]->ctx, in_host + (size_t)lo * img, hi - lo, logits_host + (size_t)lo * cls);
+    });
+}
+
+// ---- device-resident measurement path (bench.py --group): inputs generated in each member's HBM -----------------------
+int vh_group_fill_inputs_seeded(vh_group* g, uint64_t seed, int batch_per_device) {
+    if (!g || batch_per_device < 1 || batch_per_device > g->cfg.max_batch) return fail(g ? &g->err : nullptr, VH_ERR_INVALID, "bad argument");
+    const size_t in_bytes = (size_t)batch_per_device * g->cfg.image_size * g->cfg.image_size * g->cfg.channels * 4;
+    const size_t out_bytes = (size_t)batch_per_device * g->cfg.classes * 4;
+    return run_all(g, [=](int i) {
+        vh_group::Member* m = g->m[i].get();
+        if (m->resident_batch < batch_per_device) {
+            if (m->in_dev) hipFree(m->in_dev);
+            if (m->out_dev) hipFree(m->out_dev);
+            m->in_dev = m->out_dev = nullptr; m->resident_batch = 0;
+            if (hipMalloc((void**)&m->in_dev, in_bytes) != hipSuccess || hipMalloc((void**)&m->out_dev, out_bytes) != hipSuccess)
+                return fail(&m->ctx->err, VH_ERR_HIP, "vh_group_fill_inputs_seeded: out of device memory");
+            m->resident_batch = batch_per_device;
+        }
+        return vh_fill_input_seeded(m->ctx, seed + (uint64_t)i, batch_per_device, m->in_dev);   // member i = rank i's shard
+    });
+}
+
+int vh_group_forward_resident(vh_group* g, int batch_per_device, int steps) {
+    if (!g || steps < 1) return fail(g ? &g->err : nullptr, VH_ERR_INVALID, "bad argument");
+    for (auto& mp : g->m)
+        if (mp->resident_batch < batch_per_device) return fail(&g->err, VH_ERR_STATE, "call vh_group_fill_inputs_seeded first");
+    return run_all(g, [=](int i) {
+        vh_group::Member* m = g->m[i].get();
+        int rc = vh_forward_device_async(m->ctx, m->in_dev, batch_per_device, m->out_dev, steps);
+        return rc != VH_OK ? rc : vh_synchronize(m->ctx);
+    });
+}
+
+int vh_group_read_logits(vh_group* g, int batch_per_device, float* logits_host) {
+    if (!g || !logits_host) return fail(g ? &g->err : nullptr, VH_ERR_INVALID, "null argument");
+    const size_t per = (size_t)batch_per_device * g->cfg.classes;
+    return run_all(g, [=](int i) {
+        vh_group::Member* m = g->m[i].get();
+        if (m->resident_batch < batch_per_device) return fail(&m->ctx->err, VH_ERR_STATE, "no resident batch");
+        hipError_t e = hipMemcpy(logits_host + (size_t)i * per, m->out_dev, per * 4, hipMemcpyDeviceToHost);
+        return e == hipSuccess ? VH_OK : fail(&m->ctx->err, VH_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+    });
 }
 
 }  // extern "C"

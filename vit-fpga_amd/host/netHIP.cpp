@@ -47,11 +47,27 @@ namespace hip
         : n_ins((int)data.n_ins), n_layers((int)data.n_p_l.size()), n_p_l(nullptr), n_neurons(0), n_params(0),
           params(nullptr), activations(VH_ACT_RELU2), bias(nullptr), n_sets(0), gradient_init(false),
           gradient_performance(0), forward_performance(0), device_init(false), device(0), vit_mode(false),
-          vcfg(), vit_seed(0), ring_slots(0), ring_batch(0), filter_kind(VH_FILTER_BLUR3), filt_h(0), filt_w(0), mlp(nullptr), vit(nullptr), filt(nullptr)
+          vcfg(), vit_seed(0), ring_slots(0), ring_batch(0), filter_kind(VH_FILTER_BLUR3), filt_h(0), filt_w(0), mlp(nullptr), vit(nullptr), filt(nullptr), grp(nullptr)
     {
         (void)derivate; // ignored by the reference as well
+        // every check comes BEFORE the first allocation: a constructor that throws does not run its destructor
         if (n_layers <= 0 || n_ins <= 0)
             die("constructor", "net_data needs n_ins > 0 and at least one layer");
+        for (int l = 0; l < n_layers; l++)
+        {
+            const long long fan_in = (l == 0 ? (long long)data.n_ins : (long long)data.n_p_l[l - 1]);
+            if ((long long)data.n_p_l[l] <= 0 || (long long)data.n_p_l[l] > 0x7fffffff / 4)
+                die("constructor", "net_data.n_p_l entries must be positive");
+            if (!random)
+            {
+                if (data.params.size() <= (size_t)l || data.params[l].size() != data.n_p_l[l] || data.bias.size() <= (size_t)l ||
+                    data.bias[l].size() != data.n_p_l[l])
+                    die("constructor", "net_data.params / bias do not match n_p_l");
+                for (size_t j = 0; j < data.n_p_l[l]; j++)
+                    if ((long long)data.params[l][j].size() != fan_in)
+                        die("constructor", "net_data.params row length differs from the layer's fan-in");
+            }
+        }
         n_p_l = new int[n_layers];
         for (int l = 0; l < n_layers; l++)
         {
@@ -75,13 +91,8 @@ namespace hip
         for (int l = 0; l < n_layers; l++)
         {
             const int fan_in = (l == 0 ? n_ins : n_p_l[l - 1]);
-            if ((int)data.params.size() <= l || (int)data.params[l].size() != n_p_l[l] || (int)data.bias.size() <= l ||
-                (int)data.bias[l].size() != n_p_l[l])
-                die("constructor", "net_data.params / bias do not match n_p_l");
             for (int j = 0; j < n_p_l[l]; j++)
             {
-                if ((int)data.params[l][j].size() != fan_in)
-                    die("constructor", "net_data.params row length differs from the layer's fan-in");
                 memcpy(params + p, data.params[l][j].data(), sizeof(DATA_TYPE) * fan_in);
                 p += fan_in;
                 bias[q++] = data.bias[l][j];
@@ -94,7 +105,7 @@ namespace hip
         : n_ins((int)floats_per_image(cfg)), n_layers(cfg.layers), n_p_l(nullptr), n_neurons(0), n_params(0), params(nullptr),
           activations(VH_ACT_GELU), bias(nullptr), n_sets(0), gradient_init(false), gradient_performance(0),
           forward_performance(0), device_init(false), device(device_index), vit_mode(true), vcfg(cfg), vit_seed(seed),
-          ring_slots(0), ring_batch(0), filter_kind(VH_FILTER_BLUR3), filt_h(0), filt_w(0), mlp(nullptr), vit(nullptr), filt(nullptr)
+          ring_slots(0), ring_batch(0), filter_kind(VH_FILTER_BLUR3), filt_h(0), filt_w(0), mlp(nullptr), vit(nullptr), filt(nullptr), grp(nullptr)
     {
         if (vh_weight_blob_bytes(&vcfg) == 0)
             die("constructor", "unsupported vh_config");
@@ -114,10 +125,13 @@ namespace hip
             vh_mlp_destroy(mlp);
         if (vit)
             vh_destroy(vit);
+        if (grp)
+            vh_group_destroy(grp);
         if (filt)
             vh_filter_destroy(filt);
         mlp = nullptr;
         vit = nullptr;
+        grp = nullptr;
         filt = nullptr;
         device_init = false;
         delete[] n_p_l;
@@ -138,8 +152,8 @@ namespace hip
         vit_mode = rh.vit_mode; vcfg = rh.vcfg; vit_seed = rh.vit_seed; vit_blob = std::move(rh.vit_blob);
         ring_slots = rh.ring_slots; ring_batch = rh.ring_batch;
         filter_kind = rh.filter_kind; filt_h = rh.filt_h; filt_w = rh.filt_w;
-        mlp = rh.mlp; vit = rh.vit; filt = rh.filt;
-        rh.n_p_l = nullptr; rh.params = nullptr; rh.bias = nullptr; rh.mlp = nullptr; rh.vit = nullptr; rh.filt = nullptr;
+        mlp = rh.mlp; vit = rh.vit; filt = rh.filt; grp = rh.grp; devices = std::move(rh.devices);
+        rh.n_p_l = nullptr; rh.params = nullptr; rh.bias = nullptr; rh.mlp = nullptr; rh.vit = nullptr; rh.filt = nullptr; rh.grp = nullptr;
         rh.device_init = false;
     }
 
@@ -149,7 +163,7 @@ namespace hip
         activations = rh.activations; n_sets = rh.n_sets; gradient_init = rh.gradient_init;
         gradient_performance = rh.gradient_performance; forward_performance = rh.forward_performance;
         device = rh.device; vit_mode = rh.vit_mode; vcfg = rh.vcfg; vit_seed = rh.vit_seed; vit_blob = rh.vit_blob;
-        ring_slots = rh.ring_slots; ring_batch = rh.ring_batch;
+        ring_slots = rh.ring_slots; ring_batch = rh.ring_batch; devices = rh.devices;
         filter_kind = rh.filter_kind; filt_h = filt_w = 0; // the copy builds its own pipeline on first use
         if (!vit_mode)
         {
@@ -164,7 +178,7 @@ namespace hip
     }
 
     net_hip::net_hip(net_hip &&rh)
-        : n_p_l(nullptr), params(nullptr), bias(nullptr), device_init(false), mlp(nullptr), vit(nullptr), filt(nullptr)
+        : n_p_l(nullptr), params(nullptr), bias(nullptr), device_init(false), mlp(nullptr), vit(nullptr), filt(nullptr), grp(nullptr)
     {
         steal(rh);
     }
@@ -241,10 +255,52 @@ namespace hip
             device_init = true;
             return;
         }
+        if (!device_init && devices.empty())
+        {
+            // VH_DEVICES="0,1,2,3": device list from the environment (consulted once, at the first forward)
+            const char *e = getenv("VH_DEVICES");
+            for (const char *p = e; p && *p;)
+            {
+                char *end = nullptr;
+                const long v = strtol(p, &end, 10);
+                if (end == p)
+                    break;
+                devices.push_back((int)v);
+                p = (*end == ',') ? end + 1 : end;
+            }
+        }
+        if (devices.size() == 1)
+            device = devices[0];
+        if (devices.size() > 1)
+        {
+            const int n = (int)devices.size(), per = (batch + n - 1) / n;
+            if (device_init && per <= vcfg.max_batch)
+                return;
+            if (ring_slots > 0)
+                die("launch_forward", "the submit/collect pipeline is a single-device feature (set_devices with one device)");
+            if (grp)
+                vh_group_destroy(grp);
+            grp = nullptr;
+            device_init = false;
+            if (per > vcfg.max_batch)
+                vcfg.max_batch = per;
+            if (vh_group_create(&vcfg, devices.data(), n, &grp) != VH_OK)
+                die("vh_group_create", vh_last_error(nullptr));
+            const int rc = vit_blob.empty() ? vh_group_init_weights_seeded(grp, vit_seed)
+                                            : vh_group_load_weights(grp, vit_blob.data(), vit_blob.size());
+            if (rc != VH_OK)
+                die("group weights", vh_group_last_error(grp));
+            device_init = true;
+            return;
+        }
         if (device_init && batch <= vcfg.max_batch)
             return;
         if (vit)
         {
+            // growing the workspace re-creates the context: batches still in the pipeline ring would be dropped silently
+            int free_slots = 0;
+            if (ring_slots > 0 && vh_ring_free_slots(vit, &free_slots) == VH_OK && free_slots != ring_slots)
+                die("launch_forward", "batches still in flight in the pipeline: collect them before a larger batch re-creates the context");
             vh_destroy(vit); // grow the workspace for a larger batch
             vit = nullptr;
             device_init = false;
@@ -269,17 +325,10 @@ namespace hip
         if (vh_blob_file_config(blob_path, &c) != VH_OK)
             throw runtime_error(string("net_hip::from_file: ") + vh_last_error(nullptr));
         c.dtype = vh_dtype;
-        FILE *f = fopen(blob_path, "rb");
-        if (!f)
-            throw runtime_error(string("net_hip::from_file: cannot open ") + blob_path);
+        // the file as a memory blob: length, header AND checksum verified by the library (same check as vh_load_weights_file)
         string bytes(vh_weight_blob_bytes(&c), '\0');
-        const size_t got = fread(&bytes[0], 1, bytes.size(), f);
-        fclose(f);
-        if (got != bytes.size())
-            throw runtime_error(string("net_hip::from_file: short read of ") + blob_path);
-        // memory form of the blob: the file's checksum words are cleared (vh_load_weights_file verifies them; here the
-        // length and header were validated by vh_blob_file_config)
-        memset(&bytes[44], 0, 20);
+        if (vh_blob_file_read(blob_path, &bytes[0], bytes.size()) != VH_OK)
+            throw runtime_error(string("net_hip::from_file: ") + vh_last_error(nullptr));
         return net_hip(c, bytes.data(), bytes.size(), device_index);
     }
 
@@ -288,8 +337,11 @@ namespace hip
         if (!vit_mode)
             die("save_weights", "only available in ViT mode (MLP mode: get_net_data())");
         ensure_device(1);
-        if (vh_save_weights_file(vit, blob_path) != VH_OK)
-            die("vh_save_weights_file", vh_last_error(vit));
+        vh_ctx *c0 = vit;
+        if (grp && vh_group_member(grp, 0, &c0, nullptr) != VH_OK)
+            die("vh_group_member", vh_group_last_error(grp));
+        if (vh_save_weights_file(c0, blob_path) != VH_OK)
+            die("vh_save_weights_file", vh_last_error(c0));
     }
 
     // ---- pipelined forward (ViT mode) ----
@@ -371,7 +423,12 @@ namespace hip
         if (vit_mode)
         {
             out.resize((size_t)count * vcfg.classes);
-            if (vh_forward(vit, inputs.data(), count, out.data()) != VH_OK)
+            if (grp)
+            {
+                if (vh_group_forward(grp, inputs.data(), count, out.data()) != VH_OK)
+                    die("vh_group_forward", vh_group_last_error(grp));
+            }
+            else if (vh_forward(vit, inputs.data(), count, out.data()) != VH_OK)
                 die("vh_forward", vh_last_error(vit));
         }
         else
@@ -384,6 +441,17 @@ namespace hip
         forward_performance = chrono::duration_cast<chrono::microseconds>(chrono::high_resolution_clock::now() - start).count();
 #endif
         return out;
+    }
+
+    void net_hip::set_devices(const vector<int> &device_ordinals)
+    {
+        if (!vit_mode)
+            die("set_devices", "only available in ViT mode");
+        if (device_init)
+            die("set_devices", "call it before the first forward");
+        if (device_ordinals.empty())
+            die("set_devices", "empty device list");
+        devices = device_ordinals;
     }
 
     double net_hip::last_kernel_ms()

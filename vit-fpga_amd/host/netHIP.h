@@ -17,13 +17,17 @@
 //     aocl_utils::checkError); set the environment variable VH_FATAL=1 to get print + exit(1);
 //   - per-instance device state (the reference keeps namespace globals shared by all instances);
 //   - members are initialised, the rule-of-five members really copy/move, get_net_data() is the
-//     exact inverse of the constructor (netFPGA.cpp:122-124, 176-199, 206-237 are UB / TODO there).
+//     exact inverse of the constructor (netFPGA.cpp:122-124, 176-199, 206-237 are UB / TODO there);
+//   - launch_forward's input length: the reference reads the first n_ins values of whatever it is given
+//     (netFPGA.cpp:265-267); here inputs.size() must be a positive MULTIPLE of n_ins -- k * n_ins values are a batch of
+//     k vectors / images (the interface has no batch argument) -- and any other length is an error, not a truncation.
 #ifndef NETHIP_H
 #define NETHIP_H
 
 #include <cstdint>
 #include <netAbstract.h>
 #include <string>
+#include <vector>
 #include <vithip.h>
 
 namespace hip
@@ -63,6 +67,8 @@ namespace hip
         vh_mlp *mlp;
         vh_ctx *vit;
         vh_filter *filt;
+        std::vector<int> devices; // ViT mode: more than one entry = device group (vh_group_*), images sharded across them
+        vh_group *grp;
         void release();
         void copy_from(const net_hip &rh);
         void steal(net_hip &rh);
@@ -102,6 +108,13 @@ namespace hip
         void save_weights(const char *blob_path);
         void set_filter(int vh_filter_kind);        // VH_FILTER_*; before the first filter_image
         void set_pipeline(int slots, int max_batch_per_slot);
+        // ViT mode, several GPUs of one node behind ONE net_abstract*: launch_forward shards the batch's images over the
+        // listed devices (contiguous ranges, weights broadcast once over xGMI, no data-path collective; vithip.h
+        // vh_group_*).  Call before the first forward.  Without a call the environment variable VH_DEVICES (e.g.
+        // "0,1,2,3") is consulted at the first forward; a single ordinal just selects that device.  vcfg.max_batch is the
+        // per-device capacity.  The pipelined submit/collect ring is a single-device feature.
+        void set_devices(const std::vector<int> &device_ordinals);
+        size_t device_count() const { return devices.empty() ? 1 : devices.size(); }
         bool submit_forward(const std::vector<DATA_TYPE> &inputs);
         std::vector<DATA_TYPE> collect_forward();
     };

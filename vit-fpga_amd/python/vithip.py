@@ -15,6 +15,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.environ.get("VITHIP_LIB") or os.path.join(PKG_ROOT, "libvithip.so")   # VITHIP_LIB: A/B builds (tools/)
 
 DTYPE_BF16, DTYPE_FP16, DTYPE_FP8 = 0, 1, 2
+FLAG_LN_FOLD_OFF, FLAG_LN_FOLD_ON = 1, 2   # vh_config.flags
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH, EPI_LNFOLD, EPI_LNFOLD_GELU, EPI_RESID_LN = range(8)
 ACT_IDENTITY, ACT_RELU2, ACT_RELU, ACT_HARDTANH, ACT_GELU = range(5)
 
@@ -32,7 +33,7 @@ class Config(C.Structure):
     _fields_ = [("image_size", C.c_int32), ("patch_size", C.c_int32), ("channels", C.c_int32),
                 ("dim", C.c_int32), ("heads", C.c_int32), ("mlp_dim", C.c_int32),
                 ("layers", C.c_int32), ("classes", C.c_int32), ("dtype", C.c_int32),
-                ("max_batch", C.c_int32), ("ln_eps", C.c_float), ("reserved", C.c_int32)]
+                ("max_batch", C.c_int32), ("ln_eps", C.c_float), ("flags", C.c_int32)]
 
 
 # every exported symbol of include/vithip.h: name -> (restype, argtypes)
@@ -50,6 +51,7 @@ SYMBOLS = {
     "vh_create": (_i, [C.POINTER(Config), _i, C.POINTER(_vp)]),
     "vh_destroy": (_i, [_vp]),
     "vh_get_config": (_i, [_vp, C.POINTER(Config)]),
+    "vh_get_ln_fold": (_i, [_vp, _pi]),
     "vh_weight_blob_bytes": (_sz, [C.POINTER(Config)]),
     "vh_load_weights": (_i, [_vp, _vp, _sz]),
     "vh_load_weights_device": (_i, [_vp, _vp, _sz]),
@@ -73,6 +75,7 @@ SYMBOLS = {
     "vh_filter_last_error": (C.c_char_p, [_vp]),
     "vh_device_mem_info": (_i, [_i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "vh_blob_file_config": (_i, [C.c_char_p, C.POINTER(Config)]),
+    "vh_blob_file_read": (_i, [C.c_char_p, _vp, _sz]),
     "vh_save_weights_file": (_i, [_vp, C.c_char_p]),
     "vh_load_weights_file": (_i, [_vp, C.c_char_p]),
     "vh_ring_create": (_i, [_vp, _i, _i]),
@@ -102,6 +105,19 @@ SYMBOLS = {
     "vh_op_cast": (_i, [_vp, _vp, _i64, _i, _vp]),
     "vh_op_fill": (_i, [_vp, _i64, _u64, C.c_uint32, _i, _f, _vp]),
     "vh_bench_gemm": (_i, [_i, _i64, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_double)]),
+    "vh_group_create": (_i, [C.POINTER(Config), _pi, _i, C.POINTER(_vp)]),
+    "vh_group_destroy": (_i, [_vp]),
+    "vh_group_size": (_i, [_vp, _pi]),
+    "vh_group_member": (_i, [_vp, _i, C.POINTER(_vp), _pi]),
+    "vh_group_last_error": (C.c_char_p, [_vp]),
+    "vh_group_shard_bounds": (None, [_i, _i, _i, _pi, _pi]),
+    "vh_group_load_weights": (_i, [_vp, _vp, _sz]),
+    "vh_group_init_weights_seeded": (_i, [_vp, _u64]),
+    "vh_group_broadcast_weights": (_i, [_vp]),
+    "vh_group_forward": (_i, [_vp, _vp, _i, _vp]),
+    "vh_group_fill_inputs_seeded": (_i, [_vp, _u64, _i]),
+    "vh_group_forward_resident": (_i, [_vp, _i, _i]),
+    "vh_group_read_logits": (_i, [_vp, _i, _vp]),
     "vh_mlp_create": (_i, [_i, _i, _i, _pi, _i, C.POINTER(_vp)]),
     "vh_mlp_load_params": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vh_mlp_forward": (_i, [_vp, _vp, _i, _vp]),
@@ -154,9 +170,9 @@ def device_free_bytes(device=0):
     return free.value
 
 
-def make_config(cfg, dtype=DTYPE_BF16, max_batch=1, ln_eps=1e-6):
+def make_config(cfg, dtype=DTYPE_BF16, max_batch=1, ln_eps=1e-6, flags=0):
     return Config(cfg["image_size"], cfg["patch_size"], cfg["channels"], cfg["dim"], cfg["heads"],
-                  cfg["mlp_dim"], cfg["layers"], cfg["classes"], dtype, max_batch, ln_eps, 0)
+                  cfg["mlp_dim"], cfg["layers"], cfg["classes"], dtype, max_batch, ln_eps, flags)
 
 
 # ---- 16-bit helpers (host side, for building operator inputs / reading operator outputs) -------
@@ -258,9 +274,9 @@ class FilterPipeline:
 class VitContext:
     """vh_ctx wrapper: create / load weights / forward, mirroring hip::net_hip's ViT mode."""
 
-    def __init__(self, cfg, dtype=DTYPE_BF16, max_batch=1, device=0, ln_eps=1e-6):
+    def __init__(self, cfg, dtype=DTYPE_BF16, max_batch=1, device=0, ln_eps=1e-6, flags=0):
         self.cfg, self.dtype, self.device = dict(cfg), dtype, device
-        self.c = make_config(cfg, dtype, max_batch, ln_eps)
+        self.c = make_config(cfg, dtype, max_batch, ln_eps, flags)
         h = C.c_void_p()
         _check(lib().vh_create(C.byref(self.c), device, C.byref(h)))
         self.h = h.value
@@ -280,6 +296,12 @@ class VitContext:
     @property
     def blob_bytes(self):
         return lib().vh_weight_blob_bytes(C.byref(self.c))
+
+    def ln_fold(self):
+        """True when this context folds its LayerNorms into the GEMMs (vh_config.flags, model shape, dtype)."""
+        on = C.c_int(0)
+        _check(lib().vh_get_ln_fold(self.h, C.byref(on)), self.h)
+        return bool(on.value)
 
     def load_weights(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
@@ -403,6 +425,70 @@ class VitContext:
 
     def debug_set_layers(self, n):
         _check(lib().vh_debug_set_layers(self.h, n), self.h)
+
+
+def group_shard_bounds(batch, n, r):
+    lo, hi = C.c_int(0), C.c_int(0)
+    lib().vh_group_shard_bounds(batch, n, r, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class VitGroup:
+    """vh_group wrapper: the N GPUs of one node from one process (one context + host thread per device inside
+    libvithip, one RCCL broadcast of the weight blob, contiguous image shards)."""
+
+    def __init__(self, cfg, devices, dtype=DTYPE_BF16, max_batch_per_device=1, ln_eps=1e-6, flags=0):
+        self.cfg, self.devices = dict(cfg), list(devices)
+        self.c = make_config(cfg, dtype, max_batch_per_device, ln_eps, flags)
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        _check(lib().vh_group_create(C.byref(self.c), arr, len(self.devices), C.byref(h)))
+        self.h = h.value
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = lib().vh_group_last_error(self.h)
+            raise VhError(rc, msg.decode() if msg else "?")
+
+    def close(self):
+        if self.h:
+            lib().vh_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        n = C.c_int(0)
+        self._chk(lib().vh_group_size(self.h, C.byref(n)))
+        return n.value
+
+    def load_weights(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._chk(lib().vh_group_load_weights(self.h, blob.ctypes.data, blob.nbytes))
+
+    def init_weights_seeded(self, seed):
+        self._chk(lib().vh_group_init_weights_seeded(self.h, seed))
+
+    def forward(self, images):
+        images = np.ascontiguousarray(images, dtype=np.float32)
+        out = np.empty((images.shape[0], self.cfg["classes"]), dtype=np.float32)
+        self._chk(lib().vh_group_forward(self.h, images.ctypes.data, images.shape[0], out.ctypes.data))
+        return out
+
+    def fill_inputs_seeded(self, seed, batch_per_device):
+        self._chk(lib().vh_group_fill_inputs_seeded(self.h, seed, batch_per_device))
+
+    def forward_resident(self, batch_per_device, steps=1):
+        self._chk(lib().vh_group_forward_resident(self.h, batch_per_device, steps))
+
+    def read_logits(self, batch_per_device):
+        out = np.empty((len(self.devices) * batch_per_device, self.cfg["classes"]), dtype=np.float32)
+        self._chk(lib().vh_group_read_logits(self.h, batch_per_device, out.ctypes.data))
+        return out
 
 
 class MlpContext:
