@@ -215,7 +215,7 @@ def test_fp8_is_deterministic_batch_independent_and_rejects_bad_dims():
         vithip.VitContext(S.CONFIGS["vit_tiny"], dtype=FP8, max_batch=1)   # dim 192 is not a multiple of 128
 
 
-@pytest.mark.parametrize("epi", ["bias", "gelu"])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "resid"])
 def test_gemm_persistent_form_equals_one_tile_per_workgroup_form(epi):
     """Variant 6 (persistent: a workgroup walks several tiles and prefetches the next tile's K-tiles from inside the
     epilogue; the default for the 16-bit / e4m3 results) against variant 5 on shapes with more tiles than CUs and a
@@ -224,11 +224,12 @@ def test_gemm_persistent_form_equals_one_tile_per_workgroup_form(epi):
         a, a8, w8, wq, sc, bias = _operands(M, N, K, 31)
         A, W, SC, Bv = dev(a8), dev(w8), dev(sc), dev(bias)
         outs = []
+        x0 = S.fill(M * N, 32, 4, 0).reshape(M, N) if epi == "resid" else None
         for variant in (5, 6):
-            nbytes = M * N * (2 if epi == "bias" else 1)
-            out = vithip.DeviceBuffer(nbytes)
+            nbytes = M * N * {"bias": 2, "gelu": 1, "resid": 4}[epi]
+            out = vithip.DeviceBuffer.from_numpy(x0) if epi == "resid" else vithip.DeviceBuffer(nbytes)
             vithip.op_gemm_fp8(A.ptr, W.ptr, SC.ptr, Bv.ptr, out.ptr, M, N, K,
-                               vithip.EPI_BIAS if epi == "bias" else vithip.EPI_BIAS_GELU, variant)
+                               {"bias": vithip.EPI_BIAS, "gelu": vithip.EPI_BIAS_GELU, "resid": vithip.EPI_BIAS_RESID}[epi], variant)
             outs.append(out.to_numpy(np.uint8, (nbytes,)).copy())
             out.free()
         assert np.array_equal(outs[0], outs[1]), f"{(outs[0] != outs[1]).sum()} bytes differ ({M}x{N}x{K})"

@@ -369,7 +369,7 @@ def test_gemm_resid_ln_epilogue(dt, variant):
 
 
 @pytest.mark.parametrize("dt", [vithip.DTYPE_BF16, vithip.DTYPE_FP16])
-@pytest.mark.parametrize("epi", ["bias", "gelu", "lnfold_gelu"])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "lnfold_gelu", "resid_ln"])
 def test_gemm_persistent_walks_several_tiles_per_workgroup(dt, epi):
     """The persistent ping-pong form (variant 6, the default for 16-bit results): with more tiles than CUs a workgroup
     runs 2-3 tiles back to back, prefetching the next tile's first K-tile from inside the epilogue.  Same arithmetic in
@@ -385,8 +385,19 @@ def test_gemm_persistent_walks_several_tiles_per_workgroup(dt, epi):
         outs = []
         st = np.stack([rng.standard_normal(M) * 0.1, 1.0 + rng.random(M)], axis=1).astype(np.float32)
         cvec = (rng.standard_normal(N) * 0.1).astype(np.float32)
+        x0 = (rng.random((M, N), dtype=np.float32) - 0.5) if epi == "resid_ln" else None
         for variant in (5, 6):
             out = vithip.DeviceBuffer(M * N * 2)
+            if epi == "resid_ln":
+                # fp32 read-modify-write + 16-bit copy + per-64-column row sums: all three outputs must be identical
+                xb, o16 = vithip.DeviceBuffer.from_numpy(x0), vithip.DeviceBuffer(M * N * 2)
+                parts = vithip.DeviceBuffer((N // 64) * M * 2 * 4)
+                vithip.op_gemm_ex(A.ptr, W.ptr, Bv.ptr, xb.ptr, M, N, K, vithip.EPI_RESID_LN, dt, out16_ptr=o16.ptr,
+                                  partials_ptr=parts.ptr, variant=variant)
+                outs.append(np.concatenate([xb.to_numpy(np.uint16, (M * N * 2,)), o16.to_numpy(np.uint16, (M * N,)),
+                                            parts.to_numpy(np.uint16, ((N // 64) * M * 4,))]))
+                xb.free(); o16.free(); parts.free(); out.free()
+                continue
             if epi == "lnfold_gelu":
                 vithip.op_gemm_ex(A.ptr, W.ptr, Bv.ptr, out.ptr, M, N, K, vithip.EPI_LNFOLD_GELU, dt,
                                   aux_ptr=dev(cvec).ptr, stats_ptr=dev(st).ptr, variant=variant)

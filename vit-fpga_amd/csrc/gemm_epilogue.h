@@ -21,6 +21,9 @@
 
 namespace vh {
 
+#ifndef VH_EPI_ABL
+#define VH_EPI_ABL 0   // timing-only ablation builds (tools): 1 no partial-sum stores, 2 no 16-bit copy, 4 no fp32 store, 8 no residual loads
+#endif
 #ifndef VH_EPI_NT
 #define VH_EPI_NT 1   // 16-bit / e4m3 result stores non-temporal (A/B: -DVH_EPI_NT=0 builds plain stores)
 #endif
@@ -294,7 +297,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 for (int i = 0; i < NL; ++i) {
                     int m, n;
                     const f32x4* p = line(h, i, m, n);
-                    x[i] = m < M ? *p : f32x4{0.f, 0.f, 0.f, 0.f};
+                    x[i] = (m < M && !(VH_EPI_ABL & 8)) ? *p : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
         };
@@ -318,14 +321,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 f32x4* p = line(h, i, m, n);
                 const bool ok = m < M;
                 if constexpr (RESID) v = v + xv[h & 1][i];
-                if (ok) *p = v;
+                if (ok && !(VH_EPI_ABL & 4)) *p = v;
                 if constexpr (EPI == VH_EPI_RESID_LN) {
                     // producer side of the folded LayerNorm: 16-bit copy + (sum, sumsq) of these 64 columns.
                     // The 16 lanes of a DPP row hold one matrix row.
-                    if (ok) *(typename T::vec4*)((elem*)e.out16 + (int64_t)m * N + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    if (ok && !(VH_EPI_ABL & 2)) *(typename T::vec4*)((elem*)e.out16 + (int64_t)m * N + n) = pack4<T>(v[0], v[1], v[2], v[3]);
                     const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
                     const float s2 = row16_sum(fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]));
-                    if (ok && pc == 0) *(float2*)(e.partials + 2 * ((int64_t)(n_w >> 6) * M + m)) = make_float2(s1, s2);
+                    if (ok && pc == 0 && !(VH_EPI_ABL & 1)) *(float2*)(e.partials + 2 * ((int64_t)(n_w >> 6) * M + m)) = make_float2(s1, s2);
                 }
             }
         }

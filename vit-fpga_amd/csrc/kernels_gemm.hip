@@ -174,21 +174,21 @@ static hipError_t launch_epi(const GemmArgs& g, int variant, hipStream_t s) {
     }
 }
 
-// which ping-pong form a large shape takes.  Default: the PERSISTENT form (6: one workgroup per CU walks the tiles and
-// DMA-prefetches the next tile's first K-tile under the current epilogue) for the epilogues with a 16-bit result (q|k|v,
-// fc1: no loads inside the epilogue once its leading bias / statistics loads are in), the one-tile-per-workgroup form (5)
-// for the fp32 read-modify-write epilogues (their residual loads run through the whole epilogue, and the persistent
-// instantiation of them does not fit the register file without spills inside the K loop).  VH_GEMM_PP = 5 / 6 / 7 forces
-// one form for every epilogue (A/B runs, tests).
+// which ping-pong form a large shape takes.  Default: the PERSISTENT form (6: one workgroup per CU walks the tiles; the DMA
+// stream runs on across tile boundaries, so a tile's first K-tiles are in LDS when its loop starts and no launch gap or
+// prologue sits between tiles).  Measured on ViT-B/16 b512, same-box A/B against the one-tile-per-workgroup form (5):
+// q|k|v -9 %, fc1 -6 %, out-proj -5 %, fc2 +-0.  The launcher itself falls back to form 5 where the persistent form does not
+// apply (patch-row remap, N % 256 != 0, fewer than two K-tiles) and hands a ragged last row of tiles to it as a tile
+// range.  VH_GEMM_PP = 5 / 6 / 7 forces one form (A/B runs, tests).
 int gemm_pp_variant(int epilogue) {
+    (void)epilogue;
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("VH_GEMM_PP");
         v = e ? atoi(e) : 0;
         if (v < 5 || v > 7) v = 0;
     }
-    if (v) return v;
-    return epi_is_16bit(epilogue) ? 6 : 5;
+    return v ? v : 6;
 }
 int gemm_pick_variant(int64_t M, int N, int epilogue) {
     static int min_tiles = 0;

@@ -100,14 +100,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {  // bijective on [0, 
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
 }
 
-__device__ __forceinline__ int nk_of(int64_t row_bytes) { return (int)(row_bytes / 128); }
-
 template <typename T, int EPI, bool PERSIST, bool F8 = false, int AST = 2>
 __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                   const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
-                  void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn, int stagger VH_STAMP_PARAM) {
+                  void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn VH_STAMP_PARAM) {
     using vec8 = typename T::vec8;
 #ifdef VH_DIAG_STAMPS
     // the iteration whose stamps are kept: the workgroup's only tile, or the SECOND tile of a persistent workgroup
@@ -205,18 +203,6 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     const int wbase = wn * 8192;            // rows 64*wn ..    (inside a W stage)
 
     const int nk = (int)(row_bytes / KT_BYTES);
-
-    // Persistent form, optional: workgroups start `stagger` phases apart over one tile period.  Identical workgroups
-    // started together stay in lockstep (nothing re-shuffles them as the dispatcher does between one-tile workgroups),
-    // so all 256 epilogues -- 32 MB of stores -- would hit HBM in the same few microseconds of every tile period.
-    if constexpr (PERSIST) {
-        if (stagger > 1) {
-            const unsigned phase = (blockIdx.x >> 3) % (unsigned)stagger;
-            const unsigned long long ticks = (unsigned long long)phase * (unsigned)(nk_of(row_bytes) * 150 + 500) / (unsigned)stagger;   // 100 MHz ticks; ~1.5 us per K-tile + 5 us epilogue
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-        }
-    }
 
     // ---- prologue of the first tile: K-tiles 0 and 1 ------------------------------------------------------------
     setup_tile(t);
@@ -412,7 +398,9 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // full tiles only: ONE straight-line staged epilogue.  (With a ragged variant beside it hipcc hoisted the shared
             // leading load above the branch between the two, saw a path on which it is never waited for, and drained the
             // DMA queue -- vmcnt(0) -- before the next tile's first fragment reads overwrote its register.)
+            // (fp32 results: 16 rows x 256 B per pass, so that the 8 waves' slices fit the 32 KiB behind the stages)
             constexpr int SLICE = VH_PP_SMI * 16 * 128;
+            static_assert(VH_PP_SMI == 2, "staging region of the persistent form: 8 waves x 4 KiB");
             if constexpr (F8 && EPI == VH_EPI_BIAS_GELU)
                 gemm_epilogue8<EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, true, stage_epi, wave);
             else
@@ -458,13 +446,6 @@ static int gemm_super_columns(int tiles_n) {
     return 4;
 }
 
-// start phases of the persistent workgroups (VH_PP_STAGGER, 0 / 1 = none)
-static int gemm_stagger() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VH_PP_STAGGER"); v = e ? atoi(e) : 0; if (v < 0 || v > 64) v = 0; }
-    return v;
-}
-
 #ifdef VH_DIAG_STAMPS
 // ring of the most recent launches' stamps (host bookkeeping; one device buffer of slots x max_wgs x 8 words)
 struct DiagRec { int64_t M; int N, K, epi, f8, grid, variant; };
@@ -492,15 +473,14 @@ static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int ti
     static int lds_done[kMaxDevices] = {0};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
-                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n),
-                       PERSIST ? gemm_stagger() : 0
+                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n)
                        VH_STAMP_ARG(g, EPI, F8, grid, PERSIST ? 6 : (AST == 3 ? 7 : 5)));
     return hipGetLastError();
 }
 
 template <typename T, int EPI, bool F8>
 static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
-    if constexpr (!epi_is_16bit(EPI)) { if (mode == 1) mode = 0; }   // see below
+    if constexpr (EPI == VH_EPI_PATCH) { if (mode == 1) mode = 0; }   // the patch-row remap has no staged (full-line) epilogue
     const int tiles_m = (int)((g.M + 255) / 256), tiles_n = (g.N + 255) / 256;
     int ntiles = tiles_m * tiles_n;
     if (g.tile_count > 0) {   // a sub-range of the tiles (one tile per workgroup forms only)
@@ -510,10 +490,7 @@ static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
         return hipErrorInvalidValue;
     }
     if (mode == 2) return launch_pp_one<T, EPI, F8, false, 3>(g, ntiles, tiles_m, tiles_n, s);
-    // persistent form: 16-bit-result epilogues only (the fp32 read-modify-write epilogues do not fit the register file in
-    // that form: spill reloads inside the K loop are vector-memory operations and would break its counted waits), so a
-    // request for it with another epilogue takes the one-tile-per-workgroup form
-    if constexpr (epi_is_16bit(EPI)) {
+    if constexpr (EPI != VH_EPI_PATCH) {
         // the persistent form runs FULL tiles of at least two K-tiles only: N must be a multiple of the tile, and a ragged
         // last row of tiles (M % 256 != 0) goes to the one-tile-per-workgroup form as a tile range behind it
         const int full_m = (int)(g.M / 256);
@@ -563,8 +540,8 @@ hipError_t launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
     switch (g.epilogue) {
         case VH_EPI_BIAS: return launch_pp<BF16, VH_EPI_BIAS, true>(g, mode, s);
         case VH_EPI_BIAS_GELU: return launch_pp<BF16, VH_EPI_BIAS_GELU, true>(g, mode, s);
-        case VH_EPI_BIAS_RESID: return launch_pp<BF16, VH_EPI_BIAS_RESID, true>(g, mode == 1 ? 0 : mode, s);
-        case VH_EPI_BIAS_F32: return launch_pp<BF16, VH_EPI_BIAS_F32, true>(g, mode == 1 ? 0 : mode, s);
+        case VH_EPI_BIAS_RESID: return launch_pp<BF16, VH_EPI_BIAS_RESID, true>(g, mode, s);
+        case VH_EPI_BIAS_F32: return launch_pp<BF16, VH_EPI_BIAS_F32, true>(g, mode, s);
         default: return hipErrorInvalidValue;
     }
 }

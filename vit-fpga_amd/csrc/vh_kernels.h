@@ -33,7 +33,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t stream);
 hipError_t launch_gemm_fp8(const GemmArgs& g, hipStream_t stream);
 const char* gemm_check(const GemmArgs& g);  // NULL if the shape is supported, else the reason
 int gemm_pick_variant(int64_t M, int N, int epilogue);
-int gemm_pp_variant(int epilogue);  // 5, 6 or 7 (default: 6 for 16-bit results, 5 for fp32 results; env VH_GEMM_PP forces one)
+int gemm_pp_variant(int epilogue);  // 5, 6 or 7 (default 6 = persistent; env VH_GEMM_PP forces one)
 
 hipError_t launch_layernorm(const float* x, int64_t rows, int dim, int64_t row_stride,
                             const float* gamma, const float* beta, float eps, void* out16,
