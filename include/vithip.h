@@ -223,6 +223,9 @@ int vh_debug_set_layers(vh_ctx* ctx, int n_layers);
 #define VH_EPI_LNFOLD 5      /* out16[m,n]  = rstd[m]*(acc - mean[m]*c[n]) + d[n]   (LayerNorm folded: bias = d, aux = c) */
 #define VH_EPI_LNFOLD_GELU 6 /* gelu of the above                                          */
 #define VH_EPI_RESID_LN 7    /* out32 += acc + bias; out16 = 16-bit copy; partials[N/64][M][2] = row (sum, sumsq) */
+#define VH_EPI_RESID_SPLIT 8 /* residual kept as TWO 16-bit planes, x = hi + lo: (hi, lo) += acc + bias with hi = T(x), lo = T(x - hi);
+                                out = hi plane (the next GEMM's A operand), out16 = lo plane, partials as RESID_LN.  4 B per
+                                element each way instead of 4 B + the 2 B copy of RESID_LN */
 /* out = epilogue(A[M,K] * W[N,K]^T); A and W hold `dtype` elements, K contiguous.
  * aux: EPI_PATCH -> pos-emb fp32 [tokens, N] with aux_i = patches per image.
  * variant: 0 = auto, 1 = 128x128 tile, 2 = 256x256 two-stage, 5 = 256x256 ping-pong, 6 = persistent ping-pong. */
@@ -240,7 +243,7 @@ int vh_op_gemm_fp8(const void* a8, const void* w8, const float* w_scale, const f
 int vh_op_quantize_rows(const float* w, int rows, int cols, float post_scale, void* w8, float* scale, void* stream);
 
 /* same with the operands of the LayerNorm-folding epilogues: stats [M][2] = (mean, rstd) for LNFOLD*,
- * out16 [M,N] and partials [N/64][M][2] for RESID_LN (N must be a multiple of 256) */
+ * out16 [M,N] and partials [N/64][M][2] for RESID_LN / RESID_SPLIT (N must be a multiple of 256) */
 int vh_op_gemm_ex(const void* a16_dev, const void* w16_dev, const float* bias_dev, void* out_dev,
                   int64_t M, int N, int K, int epilogue, const float* aux_dev, int aux_i,
                   const float* stats_dev, void* out16_dev, float* partials_dev,
@@ -252,6 +255,9 @@ int vh_op_rowstats_cast(const float* x_dev, int64_t rows, int dim, float eps, vo
                         int dtype, void* stream);
 int vh_op_finalize_stats(const float* partials_dev, int nblk, int64_t rows, int dim, float eps, float* stats_dev,
                          void* stream);
+/* x fp32 [rows, dim] -> the two 16-bit planes of the split residual (hi = T(x), lo = T(x - hi)) and stats [rows][2] */
+int vh_op_rowstats_split(const float* x_dev, int64_t rows, int dim, float eps, void* hi_dev, void* lo_dev, float* stats_dev,
+                         int dtype, void* stream);
 /* W'[n,k] = dtype(scale * gamma[k] * W[n,k]); c[n] = sum_k W'[n,k]; d[n] = scale * (sum_k beta[k] W[n,k] + b[n]) */
 int vh_op_fold_ln(const float* w_dev, const float* b_dev, const float* gamma_dev, const float* beta_dev, int rows,
                   int dim, float scale, void* w16_dev, float* c_dev, float* d_dev, int dtype, void* stream);

@@ -368,8 +368,60 @@ def test_gemm_resid_ln_epilogue(dt, variant):
     assert np.abs(p[:, :, 1].T - (g64 ** 2).sum(2)).max() <= 1e-4 * (g64 ** 2).sum(2).max()
 
 
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_resid_split_epilogue(dt, variant):
+    """The residual stream as two 16-bit planes, x = hi + lo (VH_EPI_RESID_SPLIT): (hi, lo) += A W^T + bias.  Checked against
+    the oracle's fp32 update of the SAME starting value hi0 + lo0: the new hi is the 16-bit rounding of the new x, hi + lo
+    reproduces it to the planes' joint precision (2^-16 for bf16, 2^-21 for fp16, of the row's scale), the per-64-column
+    row sums are those of the new x, rows outside M are untouched (ragged M, canary rows)."""
+    M, N, K = 700, 512, 192
+    a = rnd16(S.fill(M * K, 29, 1, 0).reshape(M, K), dt)
+    w = rnd16(S.fill(N * K, 29, 2, 1, 0.1).reshape(N, K), dt)
+    bias = S.fill(N, 29, 3, 1, 0.1)
+    x0 = (S.fill((M + 2) * N, 29, 4, 0) * 3.0).reshape(M + 2, N)
+    hi0 = rnd16(x0, dt)
+    lo0 = rnd16(x0 - hi0, dt)
+    ref = (hi0 + lo0)[1:-1] + O.linear(a, w, bias)
+    hi, lo = dev(vithip.to16(hi0, dt)), dev(vithip.to16(lo0, dt))
+    parts = vithip.DeviceBuffer((N // 64) * M * 8)
+    vithip.op_gemm_ex(dev(vithip.to16(a, dt)).ptr, dev(vithip.to16(w, dt)).ptr, dev(bias).ptr, hi.ptr + N * 2, M, N, K,
+                      vithip.EPI_RESID_SPLIT, dt, out16_ptr=lo.ptr + N * 2, partials_ptr=parts.ptr, variant=variant)
+    h = vithip.from16(hi.to_numpy(np.uint16, (M + 2, N)), dt)
+    l = vithip.from16(lo.to_numpy(np.uint16, (M + 2, N)), dt)
+    for plane, before in ((h, hi0), (l, lo0)):
+        assert np.array_equal(plane[0], before[0]) and np.array_equal(plane[-1], before[-1])   # canary rows
+    got = h[1:-1].astype(np.float64) + l[1:-1]
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= (2.0 ** -15 if dt == vithip.DTYPE_BF16 else 2.0 ** -20) * scale + 2e-5 * scale
+    # hi is the 16-bit rounding of the updated value (up to the last-bit effect of the GEMM's summation order)
+    assert (np.abs(h[1:-1] - ref) <= ULP[dt] * np.abs(ref) * 1.01 + 2e-5 * scale).all()
+    p = parts.to_numpy(np.float32, (N // 64, M, 2))
+    g64 = got.reshape(M, N // 64, 64)
+    assert np.abs(p[:, :, 0].T - g64.sum(2)).max() <= 2e-4 * scale
+    assert np.abs(p[:, :, 1].T - (g64 ** 2).sum(2)).max() <= 1e-4 * (g64 ** 2).sum(2).max()
+
+
+def test_rowstats_split_planes_and_statistics():
+    for dt in DT:
+        rows, dim = 333, 768
+        x = (S.fill(rows * dim, 31, 5, 0) * 2.0 + 0.3).reshape(rows, dim)
+        hi, lo, st = vithip.DeviceBuffer(rows * dim * 2), vithip.DeviceBuffer(rows * dim * 2), vithip.DeviceBuffer(rows * 8)
+        vithip.op_rowstats_split(dev(x).ptr, rows, dim, 1e-6, hi.ptr, lo.ptr, st.ptr, dt)
+        h16 = hi.to_numpy(np.uint16, (rows, dim))
+        assert np.array_equal(h16, vithip.to16(x, dt))
+        h = vithip.from16(h16, dt)
+        assert np.array_equal(lo.to_numpy(np.uint16, (rows, dim)), vithip.to16(x - h, dt))
+        s = st.to_numpy(np.float32, (rows, 2))
+        x64 = x.astype(np.float64)
+        assert np.abs(s[:, 0] - x64.mean(1)).max() <= 1e-6
+        assert np.abs(s[:, 1] - 1.0 / np.sqrt(x64.var(1) + 1e-6)).max() <= 1e-5 * s[:, 1].max()
+        for b in (hi, lo, st):
+            b.free()
+
+
 @pytest.mark.parametrize("dt", [vithip.DTYPE_BF16, vithip.DTYPE_FP16])
-@pytest.mark.parametrize("epi", ["bias", "gelu", "lnfold_gelu", "resid_ln"])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "lnfold_gelu", "resid_ln", "resid_split"])
 def test_gemm_persistent_walks_several_tiles_per_workgroup(dt, epi):
     """The persistent ping-pong form (variant 6, the default for 16-bit results): with more tiles than CUs a workgroup
     runs 2-3 tiles back to back, prefetching the next tile's first K-tile from inside the epilogue.  Same arithmetic in
@@ -385,16 +437,20 @@ def test_gemm_persistent_walks_several_tiles_per_workgroup(dt, epi):
         outs = []
         st = np.stack([rng.standard_normal(M) * 0.1, 1.0 + rng.random(M)], axis=1).astype(np.float32)
         cvec = (rng.standard_normal(N) * 0.1).astype(np.float32)
-        x0 = (rng.random((M, N), dtype=np.float32) - 0.5) if epi == "resid_ln" else None
+        x0 = (rng.random((M, N), dtype=np.float32) - 0.5) if epi in ("resid_ln", "resid_split") else None
         for variant in (5, 6):
             out = vithip.DeviceBuffer(M * N * 2)
-            if epi == "resid_ln":
-                # fp32 read-modify-write + 16-bit copy + per-64-column row sums: all three outputs must be identical
-                xb, o16 = vithip.DeviceBuffer.from_numpy(x0), vithip.DeviceBuffer(M * N * 2)
+            if epi in ("resid_ln", "resid_split"):
+                # residual read-modify-write (fp32 + 16-bit copy, or the two 16-bit planes) + per-64-column row sums: every
+                # output must be identical
+                split = epi == "resid_split"
+                xb = vithip.DeviceBuffer.from_numpy(vithip.to16(x0, dt) if split else x0)
+                o16 = vithip.DeviceBuffer.from_numpy(vithip.to16(x0 - vithip.from16(vithip.to16(x0, dt), dt), dt)) if split \
+                    else vithip.DeviceBuffer(M * N * 2)
                 parts = vithip.DeviceBuffer((N // 64) * M * 2 * 4)
-                vithip.op_gemm_ex(A.ptr, W.ptr, Bv.ptr, xb.ptr, M, N, K, vithip.EPI_RESID_LN, dt, out16_ptr=o16.ptr,
-                                  partials_ptr=parts.ptr, variant=variant)
-                outs.append(np.concatenate([xb.to_numpy(np.uint16, (M * N * 2,)), o16.to_numpy(np.uint16, (M * N,)),
+                vithip.op_gemm_ex(A.ptr, W.ptr, Bv.ptr, xb.ptr, M, N, K, vithip.EPI_RESID_SPLIT if split else vithip.EPI_RESID_LN, dt,
+                                  out16_ptr=o16.ptr, partials_ptr=parts.ptr, variant=variant)
+                outs.append(np.concatenate([xb.to_numpy(np.uint16, (M * N * (1 if split else 2),)), o16.to_numpy(np.uint16, (M * N,)),
                                             parts.to_numpy(np.uint16, ((N // 64) * M * 4,))]))
                 xb.free(); o16.free(); parts.free(); out.free()
                 continue

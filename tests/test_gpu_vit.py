@@ -166,7 +166,7 @@ def test_folded_layernorm_path_agrees_with_the_separate_layernorm_path():
     a, b = outs[vithip.FLAG_LN_FOLD_ON], outs[vithip.FLAG_LN_FOLD_OFF]
     print(f"\n[fold] fp16 folded vs separate LN: {rel(a, b):.3e}")
     assert not np.array_equal(a, b)   # they really are different code paths
-    assert rel(a, b) <= NORTH_STAR
+    assert rel(a, b) <= 2 * NORTH_STAR   # each is within the tolerance of the oracle (asserted above): of each other, twice that
 
 
 def test_layer_by_layer_against_oracle():

@@ -12,6 +12,10 @@
 //        LayerNorm folded into the GEMM: with W' = gamma o W the product LN(x) W^T equals
 //        rstd * (x W'^T - mean * c) + d,  c_n = sum_k W'_nk,  d_n = sum_k beta_k W_nk + b_n, so the
 //        GEMM runs on the RAW (16-bit rounded) residual rows and the per-row statistics enter here.
+//   RESID_SPLIT             the residual stream as two 16-bit planes (x = hi + lo, hi = T(x) IS the next GEMM's operand,
+//        lo = T(x - hi): 16-17 significant bits for bf16, 22 for fp16): (hi, lo) += acc + bias, plus the per-64-column row
+//        sums of RESID_LN.  Moves 4 B per element each way where RESID_LN moves 4 B + its 2 B copy; a lane owns 8
+//        consecutive columns so that both planes move 16 B per lane.
 //   RESID_LN                out32 += acc + bias; also writes the 16-bit copy of the updated rows and,
 //        per 64-column block, the row's (sum, sum of squares) — the producer side of LNFOLD.  Together
 //        they remove the stand-alone LayerNorm pass (read 310 MB + write 155 MB per LN at ViT-B b512).
@@ -134,7 +138,7 @@ __device__ __forceinline__ f32x4 epi_value16(f32x4 acc, f32x4 bv, f32x4 cv, floa
 // ---- direct (unstaged) epilogue: ragged-N tiles, the patch-row remap, small kernels -----------------------
 template <typename T, int EPI, int MI, int NI, bool GUARD>
 __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m0, int n0) {
-    static_assert(EPI != VH_EPI_RESID_LN, "RESID_LN needs the staged path (N % tile == 0)");
+    static_assert(EPI != VH_EPI_RESID_LN && EPI != VH_EPI_RESID_SPLIT, "RESID_LN / RESID_SPLIT need the staged path (N % tile == 0)");
     using elem = typename T::elem;
     const int M = e.M, N = e.N;
     f32x4 bv[NI], cv[NI];
@@ -276,6 +280,68 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 if (MFULL || m < M) epi_store(v, (u32x4*)((elem*)e.out + (int64_t)m * N + n));
             }
         }
+    } else if constexpr (EPI == VH_EPI_RESID_SPLIT) {
+        // split residual: stage acc + bias as fp32 rows (256 B, chunk ^ (r & 15)) like the fp32 form, read back EIGHT columns per
+        // lane (two chunks), so that the hi and the lo plane are each accessed 16 B per lane / 128 B per row.  The planes of
+        // pass h+1 are loaded before pass h is processed (same reason as in the fp32 form below).
+        using vec8 = typename T::vec8;
+        constexpr int FMI = SMI / 2, NP = MI / FMI, NL = FMI * 2;
+        const int rr = lane >> 3, pc = lane & 7;
+        elem* const hi = (elem*)e.out;
+        elem* const lo = (elem*)e.out16;
+        vec8 xh[2][NL], xl[2][NL];
+        auto where = [&](int h, int i, int& m) {
+            m = m_w + h * FMI * 16 + i * 8 + rr;
+            return (int64_t)m * N + n_w + 8 * pc;
+        };
+        auto load_pass = [&](int h, vec8 (&a)[NL], vec8 (&b)[NL]) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                int m;
+                const int64_t off = where(h, i, m);
+                if (m < M && !(VH_EPI_ABL & 8)) { a[i] = *(const vec8*)(hi + off); b[i] = *(const vec8*)(lo + off); }
+                else { a[i] = vec8{}; b[i] = vec8{}; }
+            }
+        };
+        load_pass(0, xh[0], xl[0]);
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            if (h + 1 < NP) load_pass(h + 1, xh[(h + 1) & 1], xl[(h + 1) & 1]);
+#pragma unroll
+            for (int mi = 0; mi < FMI; ++mi) {
+                const int r = mi * 16 + frow;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    *(f32x4*)(sw + r * 256 + (((ni * 4 + fq) ^ (r & 15)) << 4)) = acc[h * FMI + mi][ni] + bv[ni];
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int r = i * 8 + rr;
+                const f32x4 v0 = *(const f32x4*)(sw + r * 256 + (((2 * pc) ^ (r & 15)) << 4));
+                const f32x4 v1 = *(const f32x4*)(sw + r * 256 + (((2 * pc + 1) ^ (r & 15)) << 4));
+                int m;
+                const int64_t off = where(h, i, m);
+                const bool ok = m < M;
+                float v[8];
+                vec8 hn, ln;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // hi + lo is exact in fp32 (at most 17 / 23 significant bits), then ONE rounding of the sum with the update
+                    v[j] = (j < 4 ? v0[j] : v1[j - 4]) + ((float)xh[h & 1][i][j] + (float)xl[h & 1][i][j]);
+                    hn[j] = (elem)v[j];
+                    ln[j] = (elem)(v[j] - (float)hn[j]);
+                    s1 += v[j];
+                    s2 = fmaf(v[j], v[j], s2);
+                }
+                if (ok && !(VH_EPI_ABL & 4)) { *(vec8*)(hi + off) = hn; *(vec8*)(lo + off) = ln; }
+                // the 8 lanes of a row: quad butterflies, then the mirrored half-row (lane i <-> 7 - i) joins the two quads
+                s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);     // quad_perm [1,0,3,2]
+                s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);     // quad_perm [2,3,0,1]
+                s1 += dpp_mov<0x141>(s1); s2 += dpp_mov<0x141>(s2);   // row_half_mirror
+                if (ok && pc == 0 && !(VH_EPI_ABL & 1)) *(float2*)(e.partials + 2 * ((int64_t)(n_w >> 6) * M + m)) = make_float2(s1, s2);
+            }
+        }
     } else {
         // fp32 out: rows of 64 floats = 256 B = 16 chunks, chunk ^ (r & 15); SMI/2 row blocks per pass.
         // The residual values of pass h+1 are loaded BEFORE pass h is staged, added and stored: written as
@@ -343,14 +409,14 @@ template <typename T, int EPI, int MI, int NI, int SMI = MI, bool BARRIER = true
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w, int lane,
                                               bool n_full, bool m_full, char* smem, int wave) {
     if constexpr (EPI != VH_EPI_PATCH) {
-        if (EPI == VH_EPI_RESID_LN || n_full) {
+        if (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT || n_full) {
             if constexpr (BARRIER) __syncthreads();
             if (m_full && epi_is_16bit(EPI)) gemm_epilogue_staged<T, EPI, MI, NI, SMI, true>(acc, e, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
             else gemm_epilogue_staged<T, EPI, MI, NI, SMI, false>(acc, e, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
             return;
         }
     }
-    if constexpr (EPI != VH_EPI_RESID_LN) {
+    if constexpr (EPI != VH_EPI_RESID_LN && EPI != VH_EPI_RESID_SPLIT) {
         const int m0 = m_w + (lane & 15), n0 = n_w + (lane >> 4) * 4;
         if (n_full && m_full) gemm_epilogue_impl<T, EPI, MI, NI, false>(acc, e, m0, n0);
         else gemm_epilogue_impl<T, EPI, MI, NI, true>(acc, e, m0, n0);

@@ -170,6 +170,7 @@ static hipError_t launch_epi(const GemmArgs& g, int variant, hipStream_t s) {
     case VH_EPI_LNFOLD: return launch_tile<T, VH_EPI_LNFOLD>(g, variant, s);
     case VH_EPI_LNFOLD_GELU: return launch_tile<T, VH_EPI_LNFOLD_GELU>(g, variant, s);
     case VH_EPI_RESID_LN: return launch_tile<T, VH_EPI_RESID_LN>(g, variant, s);
+    case VH_EPI_RESID_SPLIT: return launch_tile<T, VH_EPI_RESID_SPLIT>(g, variant, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -206,9 +207,10 @@ const char* gemm_check(const GemmArgs& g) {
     if (g.K % 64) return "gemm: K must be a multiple of 64";
     if (g.N % 4) return "gemm: N must be a multiple of 4";
     if (g.M > 0x7fffffff) return "gemm: M too large";
-    if (g.epilogue < 0 || g.epilogue > VH_EPI_RESID_LN) return "gemm: unknown epilogue";
+    if (g.epilogue < 0 || g.epilogue > VH_EPI_RESID_SPLIT) return "gemm: unknown epilogue";
     if ((g.epilogue == VH_EPI_LNFOLD || g.epilogue == VH_EPI_LNFOLD_GELU) && (!g.stats || !g.aux)) return "gemm: LNFOLD needs stats and c (aux)";
-    if (g.epilogue == VH_EPI_RESID_LN && (!g.out16 || !g.partials || g.N % 256)) return "gemm: RESID_LN needs out16, partials and N % 256 == 0";
+    if ((g.epilogue == VH_EPI_RESID_LN || g.epilogue == VH_EPI_RESID_SPLIT) && (!g.out16 || !g.partials || g.N % 256))
+        return "gemm: RESID_LN / RESID_SPLIT need out16, partials and N % 256 == 0";
     if (g.epilogue == VH_EPI_PATCH && (!g.aux || g.aux_i <= 0)) return "gemm: EPI_PATCH needs pos-emb and patches/image";
     if (g.dtype != VH_DTYPE_BF16 && g.dtype != VH_DTYPE_FP16) return "gemm: dtype";
     if (g.variant < 0 || g.variant > 7) return "gemm: variant";

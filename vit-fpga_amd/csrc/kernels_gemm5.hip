@@ -529,7 +529,8 @@ hipError_t launch_gemm_pingpong(const GemmArgs& g, int mode, hipStream_t s) {
     template hipError_t launch_gemm_pingpong<T, VH_EPI_PATCH>(const GemmArgs&, int, hipStream_t);       \
     template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD>(const GemmArgs&, int, hipStream_t);      \
     template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD_GELU>(const GemmArgs&, int, hipStream_t); \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_LN>(const GemmArgs&, int, hipStream_t);
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_LN>(const GemmArgs&, int, hipStream_t);   \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_SPLIT>(const GemmArgs&, int, hipStream_t);
 VH_INST(BF16)
 VH_INST(FP16)
 

@@ -291,7 +291,7 @@ hipError_t launch_dense_layer(const float* w, const float* b, const float* x, fl
 template <typename T, int CH>
 __global__ void __launch_bounds__(256)
 rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float eps, typename T::elem* __restrict__ x16,
-                     float* __restrict__ stats) {
+                     float* __restrict__ stats, typename T::elem* __restrict__ xlo) {   // xlo != NULL: the split residual's lo plane
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -315,7 +315,10 @@ rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float e
         if (c < nchunk) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; var += d * d; }
-            *(typename T::vec4*)(x16 + row * dim + 4 * c) = pack4<T>(v[i][0], v[i][1], v[i][2], v[i][3]);
+            const typename T::vec4 hq = pack4<T>(v[i][0], v[i][1], v[i][2], v[i][3]);
+            *(typename T::vec4*)(x16 + row * dim + 4 * c) = hq;
+            if (xlo) *(typename T::vec4*)(xlo + row * dim + 4 * c) = pack4<T>(v[i][0] - (float)hq[0], v[i][1] - (float)hq[1],
+                                                                           v[i][2] - (float)hq[2], v[i][3] - (float)hq[3]);
         }
     }
 #pragma unroll
@@ -324,14 +327,15 @@ rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float e
 }
 
 template <typename T>
-static hipError_t rowstats_t(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, hipStream_t s) {
+static hipError_t rowstats_t(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, hipStream_t s, void* xlo = nullptr) {
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     auto o = (typename T::elem*)x16;
-    if (dim <= 256) hipLaunchKernelGGL((rowstats_cast_kernel<T, 1>), grid, block, 0, s, x, rows, dim, eps, o, stats);
-    else if (dim <= 512) hipLaunchKernelGGL((rowstats_cast_kernel<T, 2>), grid, block, 0, s, x, rows, dim, eps, o, stats);
-    else if (dim <= 768) hipLaunchKernelGGL((rowstats_cast_kernel<T, 3>), grid, block, 0, s, x, rows, dim, eps, o, stats);
-    else if (dim <= 1024) hipLaunchKernelGGL((rowstats_cast_kernel<T, 4>), grid, block, 0, s, x, rows, dim, eps, o, stats);
-    else if (dim <= 2048) hipLaunchKernelGGL((rowstats_cast_kernel<T, 8>), grid, block, 0, s, x, rows, dim, eps, o, stats);
+    auto lo = (typename T::elem*)xlo;
+    if (dim <= 256) hipLaunchKernelGGL((rowstats_cast_kernel<T, 1>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
+    else if (dim <= 512) hipLaunchKernelGGL((rowstats_cast_kernel<T, 2>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
+    else if (dim <= 768) hipLaunchKernelGGL((rowstats_cast_kernel<T, 3>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
+    else if (dim <= 1024) hipLaunchKernelGGL((rowstats_cast_kernel<T, 4>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
+    else if (dim <= 2048) hipLaunchKernelGGL((rowstats_cast_kernel<T, 8>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -340,6 +344,48 @@ hipError_t launch_rowstats_cast(const float* x, int64_t rows, int dim, float eps
     if (rows <= 0 || dim <= 0 || (dim & 3)) return hipErrorInvalidValue;
     return dtype == VH_DTYPE_BF16 ? rowstats_t<BF16>(x, rows, dim, eps, x16, stats, s)
                                   : rowstats_t<FP16>(x, rows, dim, eps, x16, stats, s);
+}
+
+hipError_t launch_rowstats_split(const float* x, int64_t rows, int dim, float eps, void* hi, void* lo, float* stats, int dtype,
+                                 hipStream_t s) {
+    if (rows <= 0 || dim <= 0 || (dim & 3) || !lo) return hipErrorInvalidValue;
+    return dtype == VH_DTYPE_BF16 ? rowstats_t<BF16>(x, rows, dim, eps, hi, stats, s, lo)
+                                  : rowstats_t<FP16>(x, rows, dim, eps, hi, stats, s, lo);
+}
+
+// LayerNorm of selected rows of the SPLIT residual (x = hi + lo, two 16-bit planes) -> fp32: the final LayerNorm of the
+// CLS rows in front of the fp32 head.  One wave per row, two-pass statistics like layernorm_kernel.
+template <typename T>
+__global__ void __launch_bounds__(256)
+layernorm_split_kernel(const typename T::elem* __restrict__ hi, const typename T::elem* __restrict__ lo, int64_t rows, int dim,
+                       int64_t row_stride, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                       float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const typename T::elem* hr = hi + row * row_stride;
+    const typename T::elem* lr = lo + row * row_stride;
+    float sum = 0.f;
+    for (int k = lane; k < dim; k += 64) sum += (float)hr[k] + (float)lr[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)dim;
+    float var = 0.f;
+    for (int k = lane; k < dim; k += 64) { const float d = ((float)hr[k] + (float)lr[k]) - mean; var += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)dim + eps);
+    for (int k = lane; k < dim; k += 64) out[row * dim + k] = (((float)hr[k] + (float)lr[k]) - mean) * rstd * gamma[k] + beta[k];
+}
+hipError_t launch_layernorm_split(const void* hi, const void* lo, int64_t rows, int dim, int64_t row_stride, const float* gamma,
+                                  const float* beta, float eps, float* out32, int dtype, hipStream_t s) {
+    if (rows <= 0 || dim <= 0) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == VH_DTYPE_BF16)
+        hipLaunchKernelGGL(layernorm_split_kernel<BF16>, grid, block, 0, s, (const BF16::elem*)hi, (const BF16::elem*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
+    else
+        hipLaunchKernelGGL(layernorm_split_kernel<FP16>, grid, block, 0, s, (const FP16::elem*)hi, (const FP16::elem*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
+    return hipGetLastError();
 }
 
 // partials [nblk][rows][2] = (sum, sum of squares) over 64-column blocks -> stats [rows][2] = (mean, rstd).

@@ -67,6 +67,12 @@ hipError_t launch_rowstats_cast(const float* x, int64_t rows, int dim, float eps
                                 hipStream_t stream);
 hipError_t launch_finalize_stats(const float* partials, int nblk, int64_t rows, int dim, float eps, float* stats,
                                  hipStream_t stream);
+// split residual (x = hi + lo, two 16-bit planes; gemm_epilogue.h RESID_SPLIT): fp32 rows -> planes + row statistics, and
+// the fp32 LayerNorm of selected rows (the CLS rows) of the planes
+hipError_t launch_rowstats_split(const float* x, int64_t rows, int dim, float eps, void* hi, void* lo, float* stats, int dtype,
+                                 hipStream_t stream);
+hipError_t launch_layernorm_split(const void* hi, const void* lo, int64_t rows, int dim, int64_t row_stride, const float* gamma,
+                                  const float* beta, float eps, float* out32, int dtype, hipStream_t stream);
 hipError_t launch_fold_ln(const float* w, const float* b, const float* gamma, const float* beta, int rows, int dim,
                           float scale, void* w16, float* c, float* d, int dtype, hipStream_t stream);
 // MLP mode: y = act(W x + b), W [n_out, n_in] fp32

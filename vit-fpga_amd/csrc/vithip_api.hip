@@ -168,6 +168,11 @@ struct vh_ctx {
     float* fold_cd = nullptr; // per layer: cqkv[3D] dqkv[3D] c1[M] d1[M]
     float* stats = nullptr;   // [B*T][2] (mean, rstd) of the current residual rows
     float* partials = nullptr;// [D/64][B*T][2]
+    // with the fold: the residual stream lives as two 16-bit planes, x = hi + lo (hi = the xn16 buffer = the GEMMs' A operand,
+    // lo = xlo16): a residual GEMM then moves 4 B per element each way instead of the fp32 array plus its 16-bit copy.
+    // VH_RESID_SPLIT=0 (A/B tools) keeps the fp32 array.
+    bool split = false;
+    void* xlo16 = nullptr;    // [B*T, D]
     // activations (sized for max_batch)
     char* arena = nullptr;
     float* x = nullptr;       // residual stream [B*T, D] fp32
@@ -322,6 +327,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     float* const stats_p = c->stats + r0 * 2;
     float* const partials_p = c->partials + (size_t)(D / 64) * r0 * 2;
     char* const xn16 = (char*)c->xn16 + r0 * D * esz_op;
+    char* const xlo16 = (char*)c->xlo16 + r0 * D * esz;
     char* const qkv16 = (char*)c->qkv16 + r0 * 3 * D * esz;
     char* const att16 = (char*)c->att16 + r0 * D * esz_op;
     char* const h16 = (char*)c->h16 + r0 * M * esz_op;
@@ -339,7 +345,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
                     const float* aux, int aux_i) {
         GemmArgs g{a, w, bias, out, Mr, N, K, epi, aux, aux_i, dt16, 0};
         g.stats = stats_p;         // read by LNFOLD*, ignored otherwise
-        g.out16 = xn16;            // written by RESID_LN
+        g.out16 = epi == VH_EPI_RESID_SPLIT ? xlo16 : xn16;   // RESID_LN: the 16-bit copy; RESID_SPLIT: the lo plane
         g.partials = partials_p;
         return launch_gemm(g, s);
     };
@@ -365,7 +371,8 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
     if (c->ln_fold && nl > 0) {
         // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
-        HIPCHK(&c->err, launch_rowstats_cast(x, rows, D, f.ln_eps, xn16, stats_p, dt16, s));
+        if (c->split) HIPCHK(&c->err, launch_rowstats_split(x, rows, D, f.ln_eps, xn16, xlo16, stats_p, dt16, s));
+        else HIPCHK(&c->err, launch_rowstats_cast(x, rows, D, f.ln_eps, xn16, stats_p, dt16, s));
         if ((rc = mark(ST_LNSTATS))) return rc;
     }
     for (int l = 0; l < nl && c->ln_fold; ++l) {
@@ -381,7 +388,8 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
-        HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows, D, D, VH_EPI_RESID_LN, nullptr, 0));
+        if (c->split) HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, xn16, rows, D, D, VH_EPI_RESID_SPLIT, nullptr, 0));
+        else HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows, D, D, VH_EPI_RESID_LN, nullptr, 0));
         if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
         HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows, D, f.ln_eps, stats_p, s));
@@ -391,7 +399,8 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_FC1))) return rc;
         if ((rc = mark(ST_FC1))) return rc;
         if ((rc = tmark(ST_FC2))) return rc;
-        HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, x, rows, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0));
+        if (c->split) HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, xn16, rows, D, M, VH_EPI_RESID_SPLIT, nullptr, 0));
+        else HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, x, rows, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0));
         if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
         if (l + 1 < nl) {
@@ -478,7 +487,10 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = resid_gemm_ln(h16, c->w2_16[l], P + o.f2b, s2, M, more ? P + L.layer[l + 1].ln1w : nullptr,
                                 more ? P + L.layer[l + 1].ln1b : nullptr, ST_FC2))) return rc;
     }
-    HIPCHK(&c->err, launch_layernorm(x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn32, VH_DTYPE_F32_INTERNAL, s));
+    if (c->split && nl > 0)
+        HIPCHK(&c->err, launch_layernorm_split(xn16, xlo16, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn32, dt16, s));
+    else
+        HIPCHK(&c->err, launch_layernorm(x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn32, VH_DTYPE_F32_INTERNAL, s));
     if ((rc = mark(ST_LNF))) return rc;
     HIPCHK(&c->err, launch_head_f32(clsn32, P + L.headw, P + L.headb, logits, batch, f.classes, D, s));
     if ((rc = mark(ST_HEAD))) return rc;
@@ -707,6 +719,10 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     c->fp8 = cfg->dtype == VH_DTYPE_FP8;
     c->dt16 = c->fp8 ? VH_DTYPE_BF16 : cfg->dtype;
     if (c->fp8) c->ln_fold = false;
+    {
+        const char* e = getenv("VH_RESID_SPLIT");
+        c->split = c->ln_fold && !(e && e[0] == '0');
+    }
     const size_t o_cd = w16_bytes;
     w16_bytes += align_up((size_t)cfg->layers * (6 * D + 2 * M) * 4, 256);
     const size_t o_sc = w16_bytes, sc_per_layer = 5 * D + M;  // fp8: scales of q|k|v (3D), o (D), fc1 (M), fc2 (D)
@@ -729,12 +745,12 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
                  o_att = carve(rows * D * 2), o_h = carve(rows * M * 2), o_col = carve(B * L.NP * (size_t)L.KP * 2),
                  o_cls = carve(B * D * 4),
                  o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4),
-                 o_st = carve(rows * 2 * 4), o_pt = carve((D / 64 + 1) * rows * 2 * 4);
+                 o_st = carve(rows * 2 * 4), o_pt = carve((D / 64 + 1) * rows * 2 * 4), o_xlo = carve(rows * D * 2);
     CK(hipMalloc((void**)&c->arena, a));
     c->x = (float*)(c->arena + o_x); c->xn16 = c->arena + o_xn; c->qkv16 = c->arena + o_qkvA; c->att16 = c->arena + o_att;
     c->h16 = c->arena + o_h; c->col16 = c->arena + o_col; c->clsn32 = (float*)(c->arena + o_cls);
     c->in_dev = (float*)(c->arena + o_in); c->logits_dev = (float*)(c->arena + o_lg);
-    c->stats = (float*)(c->arena + o_st); c->partials = (float*)(c->arena + o_pt);
+    c->stats = (float*)(c->arena + o_st); c->partials = (float*)(c->arena + o_pt); c->xlo16 = c->arena + o_xlo;
 #undef CK
     *out = c;
     return VH_OK;
@@ -1243,6 +1259,18 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
     if (what == 0) {
         const size_t n = (size_t)c->last_batch * c->L.T * D;
         if (n_floats != n) return fail(&c->err, VH_ERR_INVALID, "expected %zu floats", n);
+        const int nl = (c->run_layers < 0 || c->run_layers > c->cfg.layers) ? c->cfg.layers : c->run_layers;
+        if (c->split && nl > 0) {   // the residual stream lives as two 16-bit planes: x = hi + lo
+            std::vector<uint16_t> hi(n), lo(n);
+            HIPCHK(&c->err, hipMemcpy(hi.data(), c->xn16, n * 2, hipMemcpyDeviceToHost));
+            HIPCHK(&c->err, hipMemcpy(lo.data(), c->xlo16, n * 2, hipMemcpyDeviceToHost));
+            auto f = [&](uint16_t b) {
+                if (c->dt16 == VH_DTYPE_BF16) { uint32_t u = (uint32_t)b << 16; float v; memcpy(&v, &u, 4); return v; }
+                _Float16 hv; memcpy(&hv, &b, 2); return (float)hv;
+            };
+            for (size_t i = 0; i < n; ++i) host_out[i] = f(hi[i]) + f(lo[i]);
+            return VH_OK;
+        }
         HIPCHK(&c->err, hipMemcpy(host_out, c->x, n * 4, hipMemcpyDeviceToHost));
         return VH_OK;
     }
@@ -1306,6 +1334,12 @@ int vh_op_gemm_ex(const void* a, const void* w, const float* bias, void* out, in
 int vh_op_rowstats_cast(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, int dtype, void* stream) {
     if (!x || !x16 || !stats || rows <= 0 || dim <= 0 || dim % 4 || dim > 2048) return fail(nullptr, VH_ERR_INVALID, "rowstats_cast: bad argument");
     OPCHK(launch_rowstats_cast(x, rows, dim, eps, x16, stats, dtype, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_rowstats_split(const float* x, int64_t rows, int dim, float eps, void* hi, void* lo, float* stats, int dtype, void* stream) {
+    if (!x || !hi || !lo || !stats || rows <= 0 || dim <= 0 || dim % 4 || dim > 2048) return fail(nullptr, VH_ERR_INVALID, "rowstats_split: bad argument");
+    OPCHK(launch_rowstats_split(x, rows, dim, eps, hi, lo, stats, dtype, (hipStream_t)stream));
     OPCHK(hipStreamSynchronize((hipStream_t)stream));
     return VH_OK;
 }

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("VITHIP_LIB") or os.path.join(PKG_ROOT, "libvithip.so"
 
 DTYPE_BF16, DTYPE_FP16, DTYPE_FP8 = 0, 1, 2
 FLAG_LN_FOLD_OFF, FLAG_LN_FOLD_ON = 1, 2   # vh_config.flags
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH, EPI_LNFOLD, EPI_LNFOLD_GELU, EPI_RESID_LN = range(8)
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH, EPI_LNFOLD, EPI_LNFOLD_GELU, EPI_RESID_LN, EPI_RESID_SPLIT = range(9)
 ACT_IDENTITY, ACT_RELU2, ACT_RELU, ACT_HARDTANH, ACT_GELU = range(5)
 
 STAGES = ["im2col", "patch_gemm", "cls_rows", "layernorm", "qkv_gemm", "attention", "proj_gemm",
@@ -98,6 +98,7 @@ SYMBOLS = {
     "vh_op_gemm_ex": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "vh_op_rowstats_cast": (_i, [_vp, _i64, _i, _f, _vp, _vp, _i, _vp]),
     "vh_op_finalize_stats": (_i, [_vp, _i, _i64, _i, _f, _vp, _vp]),
+    "vh_op_rowstats_split": (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "vh_op_fold_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "vh_op_layernorm": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _f, _vp, _i, _vp]),
     "vh_op_attention": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
@@ -563,6 +564,10 @@ def op_gemm_ex(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, dtype, aux_pt
 
 def op_rowstats_cast(x_ptr, rows, dim, eps, x16_ptr, stats_ptr, dtype):
     _check(lib().vh_op_rowstats_cast(x_ptr, rows, dim, eps, x16_ptr, stats_ptr, dtype, None))
+
+
+def op_rowstats_split(x_ptr, rows, dim, eps, hi_ptr, lo_ptr, stats_ptr, dtype):
+    _check(lib().vh_op_rowstats_split(x_ptr, rows, dim, eps, hi_ptr, lo_ptr, stats_ptr, dtype, None))
 
 
 def op_finalize_stats(partials_ptr, nblk, rows, dim, eps, stats_ptr):
