@@ -39,7 +39,8 @@ def main():
     a = ap.parse_args()
     import bench
     # the fc1 kernel: ping-pong GEMM with the GELU epilogue (epilogue id 6 = LN-fold + GELU, 1 = bias + GELU)
-    is_fc1 = lambda k: "gemm_nt_pp_kernel" in k and ("BF16, 6" in k or "BF16, 1" in k or "FP16, 6" in k or "FP16, 1" in k)
+    tn = {"bf16": "BF16", "fp16": "FP16"}[a.dtype]   # launches of the other storage type (bench.py's fp16 line) are left out
+    is_fc1 = lambda k: "gemm_nt_pp_kernel" in k and (f"{tn}, 6" in k or f"{tn}, 1" in k)
     fetch_kib, n1 = per_launch(a.fetch_dir, "FETCH_SIZE", is_fc1)
     write_kib, n2 = per_launch(a.write_dir, "WRITE_SIZE", is_fc1)
     import vh_synth as S  # noqa: E402  (tests/ is on the path through bench)
