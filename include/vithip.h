@@ -265,7 +265,9 @@ int vh_op_fold_ln(const float* w_dev, const float* b_dev, const float* gamma_dev
 int vh_op_layernorm(const float* x_dev, int64_t rows, int dim, int64_t row_stride,
                     const float* gamma_dev, const float* beta_dev, float eps, void* out16_dev,
                     int dtype, void* stream);
-/* qkv16 [batch*tokens, 3*heads*64] (q pre-scaled) -> out16 [batch*tokens, heads*64] */
+/* qkv16 [batch*tokens, 3*heads*64] -> out16 [batch*tokens, heads*64].  The q columns arrive pre-scaled by
+ * VH_ATTN_Q_SCALE = 64^-1/2 * log2(e) (the forward folds it into Wq/bq): the kernel's softmax works in the exp2 domain. */
+#define VH_ATTN_Q_SCALE 0.18033688011112042f
 int vh_op_attention(const void* qkv16_dev, int batch, int tokens, int heads, void* out16_dev,
                     int dtype, void* stream);
 /* NHWC fp32 images -> patch matrix [batch*np, patch*patch*channels] in `dtype` */

@@ -166,9 +166,14 @@ def test_layernorm_and_attention_write_e4m3():
     batch, tokens, heads = 2, 197, 4
     D = heads * 64
     qkv = O.round_bf16((S.fill(batch * tokens * 3 * D, 42, 1, 0) * 1.5).reshape(batch * tokens, 3 * D))
-    ref = O.attention(qkv, batch, tokens, heads)
+    # q columns x VH_ATTN_Q_SCALE (64^-1/2 * log2 e) rounded to bf16 as the qkv GEMM delivers them; the oracle gets the
+    # same q back in its own convention (test_gpu_ops.prescale_q)
+    q_scale = np.float32(0.125 * 1.4426950408889634)
     pre = qkv.copy()
-    pre[:, :D] *= 0.125
+    pre[:, :D] = O.round_bf16(pre[:, :D] * q_scale)
+    qkv = pre.astype(np.float64)
+    qkv[:, :D] /= np.float64(q_scale)
+    ref = O.attention(qkv.astype(np.float32), batch, tokens, heads)
     o8 = vithip.DeviceBuffer(batch * tokens * D)
     vithip.op_attention(dev(vithip.to16(pre, vithip.DTYPE_BF16)).ptr, batch, tokens, heads, o8.ptr, FP8)
     got = vithip.from_e4m3(o8.to_numpy(np.uint8, (batch * tokens, D)))

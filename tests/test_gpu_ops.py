@@ -238,6 +238,20 @@ def test_gemm_rejects_bad_shapes():
         vithip.op_gemm(b.ptr, b.ptr, b.ptr, b.ptr, 0, 16, 64, vithip.EPI_BIAS, vithip.DTYPE_BF16)   # empty
 
 
+Q_SCALE = np.float32(0.125 * 1.4426950408889634)   # VH_ATTN_Q_SCALE: 64^-1/2 * log2(e), folded into Wq by the forward
+
+
+def prescale_q(qkv, D, dt):
+    """The kernel's input (q columns x Q_SCALE, rounded to the storage type as the qkv GEMM would) and the oracle's
+    input that corresponds to it EXACTLY (the rounded q divided by the scale again, in fp32/fp64): the rounding of the
+    scaled q belongs to the GEMM in front, not to the attention kernel under test."""
+    pre = qkv.astype(np.float32).copy()
+    pre[:, :D] = rnd16(pre[:, :D] * Q_SCALE, dt)
+    ref_in = pre.astype(np.float64)
+    ref_in[:, :D] /= np.float64(Q_SCALE)   # the oracle scales by 64^-1/2 itself and works in base e
+    return pre, ref_in.astype(np.float32)
+
+
 ATT_TOL = {vithip.DTYPE_BF16: 1.2e-2, vithip.DTYPE_FP16: 1.5e-3}  # P and O are rounded to 16 bit
 
 
@@ -247,9 +261,8 @@ ATT_TOL = {vithip.DTYPE_BF16: 1.2e-2, vithip.DTYPE_FP16: 1.5e-3}  # P and O are 
 def test_attention(dt, batch, tokens, heads):
     D = heads * 64
     qkv = rnd16((S.fill(batch * tokens * 3 * D, 10, 1, 0) * 1.5).reshape(batch * tokens, 3 * D), dt)
+    pre, qkv = prescale_q(qkv, D, dt)
     ref = O.attention(qkv, batch, tokens, heads)
-    pre = qkv.copy()
-    pre[:, :D] *= 0.125  # exact: the kernel expects q pre-scaled (folded into Wq at load time)
     out = vithip.DeviceBuffer(batch * tokens * D * 2)
     vithip.op_attention(dev(vithip.to16(pre, dt)).ptr, batch, tokens, heads, out.ptr, dt)
     got = vithip.from16(out.to_numpy(np.uint16, (batch * tokens, D)), dt)
@@ -269,9 +282,8 @@ def test_attention_spiked_scores_force_rescale(dt):
     qkv[40, :D] = -3.0
     qkv[3, D:2 * D] = -3.0      # early spike for query 40, then nothing larger
     qkv = rnd16(qkv, dt)
+    pre, qkv = prescale_q(qkv, D, dt)
     ref = O.attention(qkv, batch, tokens, heads)
-    pre = qkv.copy()
-    pre[:, :D] *= 0.125
     out = vithip.DeviceBuffer(tokens * D * 2)
     vithip.op_attention(dev(vithip.to16(pre, dt)).ptr, batch, tokens, heads, out.ptr, dt)
     got = vithip.from16(out.to_numpy(np.uint16, (tokens, D)), dt)

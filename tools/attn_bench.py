@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Attention micro-benchmark (run on the GPU box): the fused attention kernel alone on the shape of a ViT forward.
+
+  python tools/attn_bench.py [--config vit_base] [--batch 512] [--dtype bf16] [--iters 20]
+
+Prints the average launch time (host clock around `iters` back-to-back launches and a copy that drains the stream) and
+the HBM rate of the algorithmic bytes (qkv read once + the output written once).  Under rocprofv3 --pmc it is the
+cheap way to get per-kernel counters without the rest of the forward.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vit-fpga_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import vh_synth as S  # noqa: E402
+import vithip  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="vit_base")
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    cfg = S.CONFIGS[a.config]
+    D, H, T = cfg["dim"], cfg["heads"], S.tokens(cfg)
+    dt = vithip.DTYPE_BF16 if a.dtype == "bf16" else vithip.DTYPE_FP16
+    n = a.batch * T * 3 * D
+    f32 = vithip.DeviceBuffer(n * 4)
+    vithip.op_fill(f32.ptr, n, 7, 1, 0, 1.0)
+    qkv = vithip.DeviceBuffer(n * 2)
+    vithip.op_cast(f32.ptr, qkv.ptr, n, dt)
+    f32.free()
+    out = vithip.DeviceBuffer(a.batch * T * D * 2)
+    drain = lambda: out.to_numpy(np.uint16, (8,))
+    for _ in range(3):
+        vithip.op_attention(qkv.ptr, a.batch, T, H, out.ptr, dt)
+    drain()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        vithip.op_attention(qkv.ptr, a.batch, T, H, out.ptr, dt)
+    drain()
+    us = (time.perf_counter() - t0) / a.iters * 1e6
+    byts = a.batch * T * 4 * D * 2
+    print(f"attention {a.config} b{a.batch} T={T} H={H} {a.dtype}: {us:8.1f} us/launch  {byts / us / 1e6:6.2f} TB/s algorithmic", flush=True)
+
+
+if __name__ == "__main__":
+    main()

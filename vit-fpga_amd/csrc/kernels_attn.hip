@@ -1,6 +1,7 @@
 // kernels_attn.hip — fused multi-head attention of the ViT hot path (gfx950).
 //
-//   out[b, t, h*64:(h+1)*64] = softmax( q_h k_h^T ) v_h        (q pre-scaled by 64^-1/2)
+//   out[b, t, h*64:(h+1)*64] = softmax( q_h k_h^T ) v_h        (q pre-scaled by 64^-1/2 * log2(e): the
+//                                                               scores leave the MFMA in the exp2 domain)
 //
 // reads the fused projection output qkv [batch*T, 3*H*64] (16-bit), writes [batch*T, H*64].
 // Head dimension is fixed at 64 (ViT-Ti/S/B/L/H all use 64).
@@ -30,7 +31,9 @@
 
 namespace vh {
 
-constexpr float kLog2e = 1.4426950408889634f;
+// the running shift of a query row is re-centred only when a tile's scores exceed it by more than 2^kTau: between
+// re-centrings p = exp2(s - shift) <= 2^kTau, which fp32 sums and 16-bit P operands (fp16 max 65504) hold easily
+constexpr float kTau = 8.0f;
 
 // lanes l and l^32 hold the two halves of a query's row: combine them with one v_permlane32_swap
 // (a VALU exchange of the wave's halves) instead of a ds_bpermute round trip through the LDS crossbar
@@ -190,7 +193,7 @@ attention_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
                 mx = cross_half_max(mx);
-                const float mnew = fmaxf(m2, mx * kLog2e);
+                const float mnew = fmaxf(m2, mx);
                 // rescale the running sums only when some row's maximum moved (exact: alpha == 1 otherwise)
                 if (__builtin_amdgcn_ballot_w64(mnew != m2)) {
                     const float alpha = __builtin_amdgcn_exp2f(m2 - mnew);
@@ -202,7 +205,7 @@ attention_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __
                 float psum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], kLog2e, -mnew));
+                    s[r] = __builtin_amdgcn_exp2f(s[r] - mnew);
                     psum += s[r];
                 }
                 lsum += psum;
@@ -251,10 +254,450 @@ attention_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __
     }
 }
 
+// ---- ring form -------------------------------------------------------------------------------------------------------
+// Persistent workgroups with ONE K/V image in LDS that is refilled tile by tile: as soon as every wave is done with
+// key tile t-1 of the current item (a workgroup barrier at the top of tile t), waves 0-3 DMA the NEXT item's tile t-1
+// into the freed slot.  K/V traffic therefore flows during the whole of an item's math instead of in a burst before
+// it (the one-shot form: load, barrier, compute, store; only the co-resident second workgroup overlapped them), at
+// the LDS cost of one image (2 workgroups per CU at T = 197, as before).  All waits are vmcnt(0) placed where the
+// youngest outstanding DMA is at least one tile old:
+//   item top        : slots 0..nt-2 (issued during the previous item) + the next Q fragments  -> barrier -> slot nt-1 issued
+//   top of tile nt-1: slot nt-1
+// Softmax without per-score shifts: q arrives scaled by 64^-1/2 * log2(e) and the score accumulators START at
+// -shift (the row's tile-0 maximum), so a tile's probabilities are exp2(acc) directly; the shift moves (rescaling
+// O and l) only when a later tile exceeds it by 2^kTau.  The last tile computes only its valid 8-key groups.
+#ifndef VH_ATTN_ABL
+#define VH_ATTN_ABL 0   // timing ablations (tools/ab_attn_abl.sh; results are wrong): 1 no exp, 2 no refill DMA, 4 no tile barriers, 8 no PV, 16 no QK, 32 no LDS reads, 64 no max
+#endif
+__device__ __forceinline__ void ring_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS reads of the slot about to be refilled are done
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+// One LDS-DMA instruction (64 lanes x 16 B -> 1 KiB at the LDS address in M0), written as inline asm on purpose: hipcc
+// makes every ds_read_b64_tr_b16 (an intrinsic without a memory operand) wait for vmcnt(0) while a global_load_lds
+// it knows of is in flight, which would drain the ring at every tile.  The kernel's own waits (ring_wait_dma) cover
+// the DMA; the compiler's vmcnt arithmetic for ordinary loads only gets stricter by not knowing these.
+__device__ __forceinline__ void ring_dma16(const void* base, uint32_t lane_off, uint32_t lds_addr) {
+    // s_nop 4: the base may have been reloaded into its SGPRs by v_readlane (SGPR spill) in the instruction before this
+    // statement; "VALU writes SGPR -> VMEM reads it" needs 5 wait states and the hazard recogniser does not look into
+    // inline asm (it also covers the one wait state between the M0 write and the LDS-DMA)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory", "m0");
+}
+#ifdef VH_DIAG_STAMPS
+// diagnostic build only (tools/attn_anatomy.py): per-wave shader-clock totals of the phases of the ring kernel
+__device__ unsigned long long g_attn_diag[1024 * 16 * 16];   // per wave: 10 phase totals, start/end s_memrealtime, hw id, 3 debug words
+__device__ __forceinline__ unsigned long long attn_rt() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long attn_ct() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define VH_ATT_T(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = attn_ct(); ph_[i] += n_ - last_; last_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define VH_ATT_T(i) do { } while (0)
+#endif
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (0..40: the counts of the staged form for up to 14 key tiles)
+__device__ __forceinline__ void ring_wait_vm(int n) {
+#define VH_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        VH_W(1) VH_W(2) VH_W(3) VH_W(4) VH_W(5) VH_W(6) VH_W(7) VH_W(8) VH_W(9) VH_W(10) VH_W(11) VH_W(12) VH_W(13) VH_W(14)
+        VH_W(15) VH_W(16) VH_W(17) VH_W(18) VH_W(19) VH_W(20) VH_W(21) VH_W(22) VH_W(23) VH_W(24) VH_W(25) VH_W(26) VH_W(27)
+        VH_W(28) VH_W(29) VH_W(30) VH_W(31) VH_W(32) VH_W(33) VH_W(34) VH_W(35) VH_W(36) VH_W(37) VH_W(38) VH_W(39) VH_W(40)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef VH_W
+}
+__device__ __forceinline__ void ring_wait_dma() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// QS ("Q staged", 96 < T <= ~208, one slab): the NEXT item's Q rows are DMA'd into an LDS staging area early in the
+// current item (tile 1) and each wave reads its four fragments from there at the item top, and the K/V images are
+// trimmed to ceil(T/8) 8-row groups (3 x 25 + 3 KiB = 78 KiB at T = 197: still two workgroups per CU).  Nothing a wave
+// waits for is then younger than about five tiles: every wait is a COUNTED vmcnt that leaves the younger DMAs and the
+// previous item's output stores in flight.  Per DMA wave and item i (nt tiles, nw waves) the issue order is
+//   item top : slot nt-1 (i)                  2      tile 1 top: Q (i+1) nw, slot 0 (i+1) 2
+//   tile t top, t = 2..nt-1: slot t-1 (i+1)   2      item end  : 8 stores
+// so a wait for X may leave outstanding:  item top (Q, slot 0): 2(nt-2) + 8;  tile 1 (slot 1): 2(nt-3) + 8 + 2;
+// tile t in 2..nt-2 (slot t): 2nt + nw + 4;  last tile (slot nt-1): nw + 2 + 2(nt-3).  The last item of a workgroup
+// issues no refills and waits with vmcnt(0).
+// QS with a ticket counter (`ticket` != null, nw >= 5): a workgroup's first two items are static (blockIdx, + grid), the
+// rest are drawn from a device counter zeroed before the launch.  The two workgroups of a CU do NOT progress equally
+// (the older one wins the issue arbitration; measured lifetimes 108-161 us for equal static shares), so equal shares
+// left every CU half empty for the last quarter of the launch.  The last wave (not a DMA wave) draws the ticket for item
+// i+2 at the top of item i; the result is picked up at the top of item i+1 (vmcnt(8): its stores are younger), handed
+// to the other waves through one LDS word across the item-top barrier, and becomes that item's prefetch target.
+template <typename T, typename TO = T, bool QS = false>
+__global__ void __launch_bounds__(1024, 4)
+attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __restrict__ out,
+                      int tokens, int heads, int slabs, int ntiles, int nitems, unsigned int* __restrict__ ticket,
+                      unsigned int heads_rcp) {
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    using vec4 = typename T::vec4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // K image, then V image; slot t = bytes [t * 4096, (t + 1) * 4096) of each.  QS: images of G = ceil(T/8) groups (the
+    // last tile's missing groups alias the start of the next area: finite data under masked keys), then the Q staging
+    // (K rows of garbage only make garbage scores for masked keys; V gets an even number of groups so that the 16-key
+    // k-step of the last tile multiplies its zero probabilities with real, finite rows)
+    const int G = (tokens + 7) >> 3, G2 = (G + 1) & ~1;
+    const int kv_bytes = QS ? G * 1024 : ntiles * 4096;          // K image = offset of the V image
+    const int q_off = kv_bytes + (QS ? G2 * 1024 : kv_bytes);    // end of the V image = offset of the Q staging (QS)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;   // LDS byte address of the ring
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int l31 = lane & 31, hl = lane >> 5;
+    const int D = heads * 64;
+    const int64_t ld = 3 * (int64_t)D;
+
+    // ---- DMA of one key tile (32 rows of K and of V = 8 pieces of 1 KiB): waves 0-3 move one K and one V piece each
+    auto kv_base = [&](int item) {
+        if (QS) {   // one slab; b = item / heads by the host's reciprocal (exact for item * heads < 2^32)
+            const int b = (int)__umulhi((unsigned)item, heads_rcp), h = item - b * heads;
+            return qkv + (int64_t)b * tokens * ld + h * 64;
+        }
+        const int bh = item / slabs;
+        const int b = bh / heads, h = bh - b * heads;
+        return qkv + (int64_t)b * tokens * ld + h * 64;
+    };
+    // Source address = wave-uniform base (scalar registers) + a 32-bit per-lane byte offset that is recomputed from the
+    // lane id at every issue (the id is laundered so that the compiler cannot hoist twelve address registers out of
+    // the item loop and spill them: a spill reload inside the loop would wait for every DMA in flight).
+    auto issue_tile = [&](const elem* base, int t) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lr_ = ln >> 3, pc_ = ln & 7;
+        // trimmed images (QS): a surplus issue re-loads the image's last group (keeps the DMA count per slot uniform)
+        const int g = 4 * t + wave;
+        const int gk = QS && g >= G ? G - 1 : g, gv = QS && g >= G2 ? G2 - 1 : g;
+        const int rowk = gk * 8 + lr_, rowv = gv * 8 + lr_;
+        const int rk = rowk < tokens ? rowk : tokens - 1;   // rows >= tokens replicate the last row
+        const int rv = rowv < tokens ? rowv : tokens - 1;
+        const int ck = pc_ ^ ((rowk >> 1) & 7);
+        const int cv = pc_ ^ (((rowv >> 1) & 1) << 2);
+        const uint32_t ok = (uint32_t)(rk * (int)ld + D + ck * 8) * 2u;
+        const uint32_t ov = (uint32_t)(rv * (int)ld + 2 * D + cv * 8) * 2u;
+        ring_dma16(base, ok, lds0 + gk * 1024);
+        ring_dma16(base, ov, lds0 + kv_bytes + gv * 1024);
+    };
+    // QS: the Q rows of an item (4 * nw groups, rows >= tokens replicate the last) -> staging, K-style swizzle
+    auto issue_q = [&](const elem* base) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lr_ = ln >> 3, pc_ = ln & 7;
+        for (int j = 0; j < nw; ++j) {
+            const int g = 4 * j + wave;
+            const int row = g * 8 + lr_;
+            const int rsrc = row < tokens ? row : tokens - 1;
+            const int ck = pc_ ^ ((row >> 1) & 7);
+            ring_dma16(base, (uint32_t)(rsrc * (int)ld + ck * 8) * 2u, lds0 + q_off + g * 1024);
+        }
+    };
+    auto load_q = [&](int item, vec8 (&qf)[4]) {
+        const int bh = item / slabs, slab = item - bh * slabs;
+        const int b = bh / heads, h = bh - b * heads;
+        int qrow = (slab * nw + wave) * 32 + l31;
+        qrow = qrow < tokens ? qrow : tokens - 1;
+        const elem* qp = qkv + ((int64_t)b * tokens + qrow) * ld + h * 64 + 8 * hl;
+        // Inline asm, in place: the item-top wait leaves the 8 output stores issued behind these loads in flight
+        // (vmcnt(8)), which hipcc's own accounting for an ordinary load cannot express across the predicated store block
+        // (it falls back to vmcnt(0) = wait for the stores just issued, every item).  ring_wait_item() orders the uses.
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                     : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]) : "v"(qp) : "memory");
+    };
+
+    // per-lane LDS addresses: K row reads (4 swizzled chunks) and the transposed V reads (two bases: the 32-column
+    // block db flips bit 6 of the swizzled byte offset)
+    const int kswz = (l31 >> 1) & 7;
+    const int g4 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+    const int vrow0 = 4 * (g4 >> 1) + tq;             // + 32*kt + 16*s (+8)
+    const int vcolb = (16 * (g4 & 1) + 4 * tp) * 2;   // byte offset inside the row, + 64*db
+    // kept as two byte offsets; the other K chunks and the second V column block are XORs of them (bits 5-6)
+    const int k0 = l31 * 128 + ((hl ^ kswz) << 4);    // chunk (2*ks + hl) ^ kswz = this ^ (ks << 5)
+    const int vx = ((vrow0 >> 1) & 1) << 6;           // same for rows +8, +16, +32*kt
+    const int v0 = kv_bytes + vrow0 * 128 + (vcolb ^ vx);   // column block 1: ^ 64  (vcolb < 64)
+
+    const int stride = (int)gridDim.x;
+    int item = blockIdx.x;
+    const elem* cbase = kv_base(item);
+    vec8 qf[4];
+    if (wave < 4) {
+        if (QS) issue_q(cbase);
+        for (int t = 0; t < ntiles; ++t) issue_tile(cbase, t);
+    }
+    if (!QS) load_q(item, qf);
+    bool first = true;
+    // QS: outstanding operations a wait may leave behind (see the table above)
+    const int w_top = 2 * (ntiles - 2) + 8, w_t1 = 2 * (ntiles - 3) + 10, w_mid = 2 * ntiles + nw + 4, w_last = nw + 2 + 2 * (ntiles - 3);
+    bool stored = false;   // did this wave issue the 8 stores of the previous item (wave-uniform)
+
+#ifdef VH_DIAG_STAMPS
+    const unsigned long long rt0_ = attn_rt();
+    unsigned int dbg_[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    int dbg_n_ = 0;
+    unsigned long long ph_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = attn_ct();
+#endif
+    const bool dyn = QS && ticket != nullptr && nw >= 5;   // wave-uniform
+    const int tk_off = q_off + 4 * nw * 1024;              // the LDS word behind the Q staging
+    unsigned int tkv = 0;                                  // ticket wave: the ticket in flight
+    while (true) {
+        int next = item + stride;
+        if (QS && dyn && !first) {
+            if (wave == nw - 1) {   // the ticket drawn at the top of the previous item (older than that item's 8 stores)
+                if (stored) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(tkv));
+                if (lane == 0) *(volatile unsigned int __attribute__((address_space(3)))*)(uintptr_t)(lds0 + tk_off) = 2u * (unsigned)stride + tkv;
+            }
+        }
+        const int b = QS ? (int)__umulhi((unsigned)item, heads_rcp) : (item / slabs) / heads;
+        const int slab = QS ? 0 : item - (item / slabs) * slabs;
+        const int h = (QS ? item : item / slabs) - b * heads;
+        const int q0 = (slab * nw + wave) * 32;
+
+        // slots 0..nt-2 of this item (first item: all) and Q have landed; the previous item's 8 output stores, the
+        // youngest operations of a wave that had rows to store, stay in flight
+        VH_ATT_T(7);   // stores, bookkeeping
+        if (QS) {
+            ring_wait_vm(first ? 0 : w_top);   // (everything it may leave behind was issued during the previous item)
+        } else {
+            if (first || !stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));   // uses of the Q fragments stay behind the wait
+        }
+        VH_ATT_T(0);   // item-top wait
+        ring_barrier();                                   // ... for every wave; everyone is done with the previous item
+        VH_ATT_T(1);   // item-top barrier
+        if (QS && dyn && !first) next = __builtin_amdgcn_readfirstlane(*(volatile const int __attribute__((address_space(3)))*)(uintptr_t)(lds0 + tk_off));
+#if defined(VH_DIAG_STAMPS) && defined(VH_ATTN_TKDBG)
+        // ticket debugging: record what the exchange delivered, but keep walking the static shares
+        if (QS && dyn && !first) { if (dbg_n_ < 3) dbg_[dbg_n_++] = (unsigned)next; next = item + stride; }
+#endif
+        const bool has_next = (unsigned)next < (unsigned)nitems;
+        const elem* nbase = kv_base(has_next ? next : item);
+        if (QS && dyn && has_next && wave == nw - 1 && lane == 0) {   // draw the ticket of the item after `next` (one lane)
+            const unsigned int one = 1u, zero = 0u;
+            // (s_nop 4: same SGPR-reload hazard as in ring_dma16 -- without it the atomic went out with a stale upper
+            //  address half and the launch died with a memory aperture violation)
+            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(tkv) : "v"(zero), "v"(one), "s"(ticket) : "memory");
+        }
+        if (!(VH_ATTN_ABL & 2) && !first && wave < 4) issue_tile(cbase, ntiles - 1);
+        if (QS) {   // this wave's Q fragments out of the staging area (free again after the barrier at the top of tile 1)
+            const int qa = q_off + wave * 4096 + k0;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const vec8*)(smem + (qa ^ (ks << 5)));
+        }
+
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        float negm = 0.f;      // - (shift of this lane's query row), exp2 domain
+        float lsum = 0.f;      // this lane's half of the row sum
+
+        // S^T tile: 32 keys x 32 queries, accumulators start at `init` (= -shift)
+        auto qk = [&](int kt, float init) {
+            // all four K fragments requested up front (hipcc, register-shy at this occupancy, otherwise reads one, waits, multiplies)
+            const int ka = k0 + kt * 4096;
+            vec8 kf[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (VH_ATTN_ABL & 32) kf[ks] = qf[ks]; else if (VH_ATTN_ABL & 128) kf[ks] = *(const vec8*)(smem + ((ka ^ (ks << 5)) & 0x3ff0)); else
+                kf[ks] = *(const vec8*)(smem + (ka ^ (ks << 5)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // 8 x v_mov_b64 of the (init, init) pair: left to itself hipcc splats with 16 v_mov_b32 + 8 v_mov_b64
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x8 __attribute__((ext_vector_type(8)));
+            const f32x2 i2 = {init, init};
+            f32x2 p[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_mov_b64 %0, %1" : "=v"(p[i]) : "v"(i2));
+            const f32x4 q0 = __builtin_shufflevector(p[0], p[1], 0, 1, 2, 3), q1 = __builtin_shufflevector(p[2], p[3], 0, 1, 2, 3);
+            const f32x4 q2 = __builtin_shufflevector(p[4], p[5], 0, 1, 2, 3), q3 = __builtin_shufflevector(p[6], p[7], 0, 1, 2, 3);
+            const f32x8 h0 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), h1 = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7);
+            f32x16 s = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (VH_ATTN_ABL & 16) s[ks] += (float)kf[ks][0] * (float)qf[ks][0];
+                else s = T::mfma32(kf[ks], qf[ks], s);
+            }
+            return s;
+        };
+        struct VFrag { vec8 f[2][2]; };   // V^T fragments of one 32-key tile: [k-step][column block]
+        auto load_v = [&](int kt) {
+            VFrag v;
+            if (VH_ATTN_ABL & 32) { for (int ks = 0; ks < 2; ++ks) { v.f[ks][0] = qf[ks]; v.f[ks][1] = qf[ks + 2]; } return v; }
+            const char* p0 = smem + (v0 + kt * 4096);
+            const char* p1 = smem + ((v0 + kt * 4096) ^ 64);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const vec4 a0 = T::tr_read(p0 + ks * 2048), c0 = T::tr_read(p0 + ks * 2048 + 1024);
+                const vec4 a1 = T::tr_read(p1 + ks * 2048), c1 = T::tr_read(p1 + ks * 2048 + 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v.f[ks][0][j] = a0[j]; v.f[ks][0][4 + j] = c0[j]; v.f[ks][1][j] = a1[j]; v.f[ks][1][4 + j] = c1[j]; }
+            }
+            return v;
+        };
+        // one tile of softmax + O^T += V^T P^T.  `s` holds scores - shift.
+        auto softmax_pv = [&](int kt, f32x16& s, const VFrag& vfr, auto first_c, auto tail_c) {
+            constexpr bool FIRST = decltype(first_c)::value, TAIL = decltype(tail_c)::value;
+            int ng = 4;                                   // 8-key groups of this tile that hold keys < tokens
+            if constexpr (TAIL) {
+                const int valid = tokens - kt * 32;
+                ng = (valid + 7) >> 3;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (g < ng) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (8 * g + j + 4 * hl >= valid) s[4 * g + j] = -INFINITY;
+                    }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (!TAIL || g < ng) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[4 * g + j]);
+                }
+            if (VH_ATTN_ABL & 64) mx = s[kt & 15];
+            else
+            mx = cross_half_max(mx);
+            if constexpr (FIRST) {
+                negm = -mx;                               // the row's shift = its maximum over tile 0
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] -= mx;
+            } else if (__builtin_amdgcn_ballot_w64(mx > kTau)) {   // rare: some row outgrew its shift by 2^kTau
+                const float delta = fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                negm -= delta;
+                lsum *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; s[r] -= delta; }
+            }
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 psum = {0.f, 0.f};                      // two chains, packed adds
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (!TAIL || g < ng) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[4 * g + j] = (VH_ATTN_ABL & 1) ? s[4 * g + j] * 0.001f + 1.0f : __builtin_amdgcn_exp2f(s[4 * g + j]);
+                    psum += f32x2{s[4 * g], s[4 * g + 1]};
+                    psum += f32x2{s[4 * g + 2], s[4 * g + 3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[4 * g + j] = 0.f;
+                }
+            }
+            lsum += psum[0] + psum[1];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (!TAIL || 2 * ks < ng) {
+                    vec8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (elem)s[8 * ks + j];
+                    if (VH_ATTN_ABL & 8) { o0[ks] += (float)pf[0]; o1[ks] += (float)vfr.f[ks][0][0] + (float)vfr.f[ks][1][0]; }
+                    else {
+                    o0 = T::mfma32(vfr.f[ks][0], pf, o0);
+                    o1 = T::mfma32(vfr.f[ks][1], pf, o1);
+                    }
+                }
+            }
+        };
+
+        // No software pipeline across tiles (it costs 16 registers this kernel does not have at 4 waves per SIMD): a
+        // wave's K reads and score MFMAs sit under the exp/max/convert streams of the SIMD's other waves.  The V
+        // fragments are requested before the score MFMAs so that they arrive during the softmax.
+        // A wave whose 32 rows all lie beyond `tokens` (T = 577: one of 20) runs the clamped last row and stores nothing:
+        // no wave-dependent control flow around the barriers, the DMA duty or the Q prefetch.
+        {
+            const VFrag vfr = load_v(0);
+            f32x16 sc = qk(0, 0.f);
+            softmax_pv(0, sc, vfr, std::true_type{}, std::false_type{});
+        }
+        VH_ATT_T(2);   // Q fetch + tile 0
+        for (int kt = 1; kt + 1 < ntiles; ++kt) {
+            if (QS) ring_wait_vm(kt == 1 ? w_t1 : !has_next ? 0 : w_mid);   // this wave's pieces of slot kt
+            VH_ATT_T(4);   // middle tiles: compute (and the wait, QS)
+            if (!(VH_ATTN_ABL & 4)) ring_barrier();       // tile kt-1 is finished everywhere
+            VH_ATT_T(3);   // middle tiles: barrier
+            if (QS && kt == 1 && has_next && wave < 4) issue_q(nbase);
+            if (!(VH_ATTN_ABL & 2) && has_next && wave < 4) issue_tile(nbase, kt - 1);
+            const VFrag vfr = load_v(kt);
+            f32x16 sc = qk(kt, negm);
+            softmax_pv(kt, sc, vfr, std::false_type{}, std::false_type{});
+        }
+        VH_ATT_T(4);
+        if (QS) ring_wait_vm(!has_next ? 0 : w_last);     // this wave's pieces of slot nt-1
+        else ring_wait_dma();                             // (youngest DMA in flight: one tile old)
+        VH_ATT_T(5);   // last-tile wait
+        if (!(VH_ATTN_ABL & 4)) ring_barrier();           // ... visible to every wave; tile nt-2 is finished everywhere
+        VH_ATT_T(6);   // last-tile barrier
+        if (!(VH_ATTN_ABL & 2) && has_next && wave < 4) issue_tile(nbase, ntiles - 2);
+        {
+            const VFrag vfr = load_v(ntiles - 1);
+            f32x16 sc = qk(ntiles - 1, negm);
+            if (!QS && has_next) load_q(next, qf);        // the last score MFMAs are issued: qf is free
+            softmax_pv(ntiles - 1, sc, vfr, std::false_type{}, std::true_type{});
+            VH_ATT_T(8);   // last tile
+
+            // ---- normalise and store: lane holds O[q][32*db + 8*rg + 4*hl + 0..3] ------------------
+            const float ltot = cross_half_sum(lsum);
+            const float inv = __builtin_amdgcn_rcpf(ltot);   // 1 ulp; the result is rounded to 16 (8) bits right after
+            const int q = q0 + l31;
+            if (q < tokens) {
+                typename TO::elem* op = out + ((int64_t)b * tokens + q) * D + h * 64 + 4 * hl;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    *(typename TO::vec4*)(op + 8 * rg) = pack4<TO>(o0[4 * rg] * inv, o0[4 * rg + 1] * inv, o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
+                    *(typename TO::vec4*)(op + 32 + 8 * rg) = pack4<TO>(o1[4 * rg] * inv, o1[4 * rg + 1] * inv, o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
+                }
+            }
+        }
+        VH_ATT_T(9);   // normalise + stores
+        if (!has_next) break;
+        stored = q0 < tokens;
+        item = next;
+        cbase = nbase;
+        first = false;
+    }
+#ifdef VH_DIAG_STAMPS
+    VH_ATT_T(7);
+    if (lane == 0 && blockIdx.x < 1024) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) g_attn_diag[((size_t)blockIdx.x * 16 + wave) * 16 + i] = ph_[i];
+        unsigned int hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_attn_diag[((size_t)blockIdx.x * 16 + wave) * 16 + 10] = rt0_;
+        g_attn_diag[((size_t)blockIdx.x * 16 + wave) * 16 + 11] = attn_rt();
+        g_attn_diag[((size_t)blockIdx.x * 16 + wave) * 16 + 12] = ((unsigned long long)xcc << 32) | hw;
+        for (int i = 0; i < 3; ++i) g_attn_diag[((size_t)blockIdx.x * 16 + wave) * 16 + 13 + i] = dbg_[i];
+    }
+#endif
+}
+
+#ifdef VH_DIAG_STAMPS
+extern "C" int vh_diag_attn_read(unsigned long long* host, int n_words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_diag), (size_t)n_words * 8);
+}
+#endif
+
 size_t attention_lds_bytes(int tokens) { return (size_t)((tokens + 31) / 32) * 8192; }
 
 template <typename T, typename TO = T>
-static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, hipStream_t s) {
+static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, unsigned int* ticket, hipStream_t s) {
     const int ntiles = (tokens + 31) / 32;
     const int nqb = ntiles;
     static int max_waves = 0;   // waves per workgroup (each owns 32 queries): VH_ATTN_WAVES, default 16 (T = 577: 10 waves share one K/V image instead of 7)
@@ -277,6 +720,38 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     static int want_persist = -1;
     if (want_persist < 0) { const char* e = getenv("VH_ATTN_PERSIST"); want_persist = e ? atoi(e) : 0; }
     const bool persist = want_persist && 2 * one <= 160 * 1024 && nitems > num_cu;
+    // ring forms (default): need the four DMA waves and at least three key tiles; VH_ATTN_RING=0 selects the one-shot
+    // form, 2 the ring without Q staging where the staged form would be used
+    static int want_ring = -1;
+    if (want_ring < 0) { const char* e = getenv("VH_ATTN_RING"); want_ring = e ? atoi(e) : 1; }
+    // staged-Q ring (counted waits): one slab of at least four waves whose trimmed images + staging fit twice in a CU
+    const int G = (tokens + 7) / 8, G2 = (G + 1) & ~1;
+    const size_t qs_lds = (size_t)(G + G2 + 4 * nw) * 1024 + 16;   // + the ticket word
+    if (std::is_same<T, TO>::value && want_ring >= 1 && want_ring != 2 && slabs == 1 && nw >= 4 && 2 * qs_lds <= 160 * 1024) {
+        auto k = attention_ring_kernel<T, TO, true>;
+        static int lds_done[kMaxDevices] = {0};
+        if (hipError_t e = ensure_dynamic_lds((const void*)k, qs_lds, lds_done); e != hipSuccess) return e;
+        const int grid = nitems < 2 * num_cu ? nitems : 2 * num_cu;
+        static int want_dyn = -1;   // VH_ATTN_DYN=0: equal static shares
+        if (want_dyn < 0) { const char* e = getenv("VH_ATTN_DYN"); want_dyn = e ? atoi(e) : 1; }
+        unsigned int* tk = want_dyn && nw >= 5 && nitems > 2 * grid ? ticket : nullptr;
+        if (tk) { if (hipError_t e = hipMemsetAsync(tk, 0, sizeof(unsigned int), s); e != hipSuccess) return e; }
+        const unsigned int heads_rcp = (unsigned int)(((1ull << 32) + (unsigned)heads - 1) / (unsigned)heads);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(nw * 64), qs_lds, s, (const typename T::elem*)qkv, (typename TO::elem*)out,
+                           tokens, heads, slabs, ntiles, nitems, tk, heads_rcp);
+        return hipGetLastError();
+    }
+    if (want_ring && ntiles >= 3 && nw >= 4) {
+        auto k = attention_ring_kernel<T, TO, false>;
+        static int lds_done[kMaxDevices] = {0};
+        if (hipError_t e = ensure_dynamic_lds((const void*)k, one, lds_done); e != hipSuccess) return e;
+        const int per_cu = (int)(160 * 1024 / one);       // co-resident workgroups per CU by LDS
+        int grid = num_cu * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+        if (grid > nitems) grid = nitems;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(nw * 64), one, s, (const typename T::elem*)qkv, (typename TO::elem*)out,
+                           tokens, heads, slabs, ntiles, nitems, (unsigned int*)nullptr, 0u);
+        return hipGetLastError();
+    }
     if constexpr (!std::is_same<T, TO>::value) {
         auto k = attention_kernel<T, false, TO>;
         static int lds_done[kMaxDevices] = {0};
@@ -306,11 +781,11 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
 }
 
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype,
-                            hipStream_t s) {
+                            unsigned int* ticket, hipStream_t s) {
     if (batch <= 0 || tokens <= 0 || heads <= 0) return hipErrorInvalidValue;
-    if (dtype == VH_DTYPE_FP8) return launch_attn_t<BF16, E4M3>(qkv16, batch, tokens, heads, out16, s);  // bf16 in, e4m3 out
-    return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16>(qkv16, batch, tokens, heads, out16, s)
-                                  : launch_attn_t<FP16>(qkv16, batch, tokens, heads, out16, s);
+    if (dtype == VH_DTYPE_FP8) return launch_attn_t<BF16, E4M3>(qkv16, batch, tokens, heads, out16, ticket, s);  // bf16 in, e4m3 out
+    return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16>(qkv16, batch, tokens, heads, out16, ticket, s)
+                                  : launch_attn_t<FP16>(qkv16, batch, tokens, heads, out16, ticket, s);
 }
 
 }  // namespace vh

@@ -59,14 +59,14 @@ struct F32OUT {
     using vec4 = f32x4;
 };
 
+// four fp32 -> one 8-byte vector of the storage type.  Converted as two PAIRS: element-wise casts made hipcc emit one
+// single conversion per value plus v_perm/v_alignbit to assemble the halves (3 instructions per pair instead of 1).
 template <typename T>
 __device__ __forceinline__ typename T::vec4 pack4(float a, float b, float c, float d) {
-    typename T::vec4 v;
-    v[0] = (typename T::elem)a;
-    v[1] = (typename T::elem)b;
-    v[2] = (typename T::elem)c;
-    v[3] = (typename T::elem)d;
-    return v;
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef typename T::elem e2_ __attribute__((ext_vector_type(2)));
+    const e2_ lo = __builtin_convertvector(f32x2_{a, b}, e2_), hi = __builtin_convertvector(f32x2_{c, d}, e2_);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 
 // 8-bit OUTPUT type of the fp8 path (VH_DTYPE_FP8): OCP e4m3fn, no scale, saturating at +-448.

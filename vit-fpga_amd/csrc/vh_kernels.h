@@ -43,8 +43,13 @@ constexpr int VH_DTYPE_F32_INTERNAL = 100;
 // classifier head, fp32 operands (exact-fp32 MFMA): logits[b, c] = y[b, :] . w[c, :] + bias[c]; classes % 4 == 0, dim % 16 == 0
 hipError_t launch_head_f32(const float* y, const float* w, const float* bias, float* out, int batch, int classes, int dim,
                            hipStream_t stream);
+// q columns of qkv16 arrive scaled by kAttnQScale = 64^-1/2 * log2(e) (folded into Wq and bq when the weights are
+// prepared): the score MFMAs then produce log2-domain scores and the softmax is exp2 without a multiply per score
+constexpr float kAttnQScale = 0.125f * 1.4426950408889634f;
+// ticket: 4 bytes of device scratch owned by the caller's stream (zeroed by the launch; work-queue counter of the
+// staged ring form), or nullptr for equal static shares per workgroup
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16,
-                            int dtype, hipStream_t stream);
+                            int dtype, unsigned int* ticket, hipStream_t stream);
 size_t attention_lds_bytes(int tokens);
 hipError_t launch_im2col(const float* in_nhwc, int batch, int image, int patch, int channels,
                          void* out16, int dtype, hipStream_t stream);

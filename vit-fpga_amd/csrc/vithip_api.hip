@@ -175,6 +175,7 @@ struct vh_ctx {
     void* xlo16 = nullptr;    // [B*T, D]
     // activations (sized for max_batch)
     char* arena = nullptr;
+    unsigned int* tickets = nullptr;   // [max_batch] work-queue counters of the attention kernel (launch_attention)
     float* x = nullptr;       // residual stream [B*T, D] fp32
     void* xn16 = nullptr;     // LN output       [B*T, D]
     void* qkv16 = nullptr;    //                 [B*T, 3D]
@@ -263,12 +264,12 @@ int prepare_weights(vh_ctx* c) {
     for (int l = 0; l < f.layers && c->fp8; ++l) {
         const LayerOff& o = L.layer[l];
         // bias [bq/8 ; bk ; bv] from the 16-bit packer (its 16-bit matrix is overwritten right after), then
-        // e4m3 rows + scales; the softmax scale 1/8 goes into the q rows' scales (a power of two: exact)
-        HIPCHK(&c->err, launch_pack_qkv(P + o.qw, P + o.qb, P + o.kw, P + o.kb, P + o.vw, P + o.vb, D, 0.125f,
+        // e4m3 rows + scales; the softmax scale 64^-1/2 * log2(e) (kAttnQScale) goes into the q rows' fp32 scales
+        HIPCHK(&c->err, launch_pack_qkv(P + o.qw, P + o.qb, P + o.kw, P + o.kb, P + o.vw, P + o.vb, D, kAttnQScale,
                                         c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, c->dt16, s));
         char* wq = (char*)c->wqkv16[l];
         const size_t dd = (size_t)D * D;
-        HIPCHK(&c->err, launch_quantize_rows(P + o.qw, D, D, 0.125f, wq, c->sqkv[l], s));
+        HIPCHK(&c->err, launch_quantize_rows(P + o.qw, D, D, kAttnQScale, wq, c->sqkv[l], s));
         HIPCHK(&c->err, launch_quantize_rows(P + o.kw, D, D, 1.0f, wq + dd, c->sqkv[l] + D, s));
         HIPCHK(&c->err, launch_quantize_rows(P + o.vw, D, D, 1.0f, wq + 2 * dd, c->sqkv[l] + 2 * D, s));
         HIPCHK(&c->err, launch_quantize_rows(P + o.ow, D, D, 1.0f, c->wo16[l], c->so[l], s));
@@ -278,16 +279,16 @@ int prepare_weights(vh_ctx* c) {
     for (int l = 0; l < f.layers && !c->fp8; ++l) {
         const LayerOff& o = L.layer[l];
         if (c->ln_fold) {
-            // W' = gamma o W (q rows also carry the softmax scale), c = row sums of W', d = beta.W + b
+            // W' = gamma o W (q rows also carry the softmax scale kAttnQScale), c = row sums of W', d = beta.W + b
             float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
             char* wq = (char*)c->wqkv16[l];
             const size_t dd2 = (size_t)D * D * 2;
-            HIPCHK(&c->err, launch_fold_ln(P + o.qw, P + o.qb, P + o.ln1w, P + o.ln1b, D, D, 0.125f, wq, cd, cd + 3 * D, f.dtype, s));
+            HIPCHK(&c->err, launch_fold_ln(P + o.qw, P + o.qb, P + o.ln1w, P + o.ln1b, D, D, kAttnQScale, wq, cd, cd + 3 * D, f.dtype, s));
             HIPCHK(&c->err, launch_fold_ln(P + o.kw, P + o.kb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + dd2, cd + D, cd + 4 * D, f.dtype, s));
             HIPCHK(&c->err, launch_fold_ln(P + o.vw, P + o.vb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + 2 * dd2, cd + 2 * D, cd + 5 * D, f.dtype, s));
             HIPCHK(&c->err, launch_fold_ln(P + o.f1w, P + o.f1b, P + o.ln2w, P + o.ln2b, M, D, 1.0f, c->w1_16[l], cd + 6 * D, cd + 6 * D + M, f.dtype, s));
         } else {
-            HIPCHK(&c->err, launch_pack_qkv(P + o.qw, P + o.qb, P + o.kw, P + o.kb, P + o.vw, P + o.vb, D, 0.125f,
+            HIPCHK(&c->err, launch_pack_qkv(P + o.qw, P + o.qb, P + o.kw, P + o.kb, P + o.vw, P + o.vb, D, kAttnQScale,
                                             c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, f.dtype, s));
             HIPCHK(&c->err, launch_cast(P + o.f1w, c->w1_16[l], (int64_t)M * D, f.dtype, s));
         }
@@ -384,7 +385,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, dt16, s));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, dt16, c->tickets + img0, s));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
@@ -475,7 +476,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, op_dt, s));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, op_dt, c->tickets + img0, s));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = resid_gemm_ln(att16, c->wo16[l], P + o.ob, so, D, P + o.ln2w, P + o.ln2b, ST_PROJ))) return rc;
@@ -745,12 +746,14 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
                  o_att = carve(rows * D * 2), o_h = carve(rows * M * 2), o_col = carve(B * L.NP * (size_t)L.KP * 2),
                  o_cls = carve(B * D * 4),
                  o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4),
-                 o_st = carve(rows * 2 * 4), o_pt = carve((D / 64 + 1) * rows * 2 * 4), o_xlo = carve(rows * D * 2);
+                 o_st = carve(rows * 2 * 4), o_pt = carve((D / 64 + 1) * rows * 2 * 4), o_xlo = carve(rows * D * 2),
+                 o_tk = carve(B * 4);   // attention work-queue counters: one word per image, a part uses its first image's
     CK(hipMalloc((void**)&c->arena, a));
     c->x = (float*)(c->arena + o_x); c->xn16 = c->arena + o_xn; c->qkv16 = c->arena + o_qkvA; c->att16 = c->arena + o_att;
     c->h16 = c->arena + o_h; c->col16 = c->arena + o_col; c->clsn32 = (float*)(c->arena + o_cls);
     c->in_dev = (float*)(c->arena + o_in); c->logits_dev = (float*)(c->arena + o_lg);
     c->stats = (float*)(c->arena + o_st); c->partials = (float*)(c->arena + o_pt); c->xlo16 = c->arena + o_xlo;
+    c->tickets = (unsigned int*)(c->arena + o_tk);
 #undef CK
     *out = c;
     return VH_OK;
@@ -1368,7 +1371,13 @@ int vh_op_attention(const void* qkv16, int batch, int tokens, int heads, void* o
     if (!qkv16 || !out16) return fail(nullptr, VH_ERR_INVALID, "null pointer");
     if (batch <= 0 || tokens <= 0 || heads <= 0 || attention_lds_bytes(tokens) > 160 * 1024)
         return fail(nullptr, VH_ERR_INVALID, "attention: unsupported shape");
-    OPCHK(launch_attention(qkv16, batch, tokens, heads, out16, dtype, (hipStream_t)stream));
+    // the operator tap owns one counter per device (taps run one at a time; a context carries its own in its arena)
+    static unsigned int* tap_ticket[kMaxDevices] = {nullptr};
+    int dev = 0;
+    OPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(nullptr, VH_ERR_INVALID, "attention: device ordinal out of range");
+    if (!tap_ticket[dev]) OPCHK(hipMalloc((void**)&tap_ticket[dev], 256));
+    OPCHK(launch_attention(qkv16, batch, tokens, heads, out16, dtype, tap_ticket[dev], (hipStream_t)stream));
     OPCHK(hipStreamSynchronize((hipStream_t)stream));
     return VH_OK;
 }
