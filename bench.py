@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp8"],
                     help="fp8 = BASELINE config 5: e4m3 operands for the four per-layer GEMMs (bf16 elsewhere)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
+    ap.add_argument("--weights", default="full", choices=["full", "e4m3"],
+                    help="e4m3: weight-only fp8, VH_FLAG_W8_E4M3 (q/k/v/o/fc1/fc2 through the e4m3 row quantiser at load; 16-bit dtypes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed batch's first images")
     ap.add_argument("--parity-images", type=int, default=16)
@@ -129,7 +131,8 @@ def main():
         """One complete measurement with `dtype_name` operands: context, weights (broadcast when distributed), warm-up,
         K timed steps, roofline of the fc1 kernel, parity of the timed batch's first images."""
         dt = {"bf16": vithip.DTYPE_BF16, "fp16": vithip.DTYPE_FP16, "fp8": vithip.DTYPE_FP8}[dtype_name]
-        ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B, device=local_rank)
+        ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B, device=local_rank,
+                                flags=vithip.FLAG_W8_E4M3 if args.weights == "e4m3" else 0)
         if args.streams > 0:
             ctx.set_streams(args.streams)
         streams = ctx.get_streams()
@@ -232,7 +235,8 @@ def main():
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config} {cfg['image_size']}x{cfg['image_size']}x{cfg['channels']} inference, "
-                                   f"{B} images per GPU resident in HBM, random-init weights (seed 0)",
+                                   f"{B} images per GPU resident in HBM, random-init weights (seed 0)"
+                                   + (", weight-only e4m3 (VH_FLAG_W8_E4M3)" if args.weights == "e4m3" else ""),
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": par, "flop_per_image": flops_img},
             "forward_mfma_frac": main_res["forward_mfma_frac"],
             "roofline": main_res["roofline"],

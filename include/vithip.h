@@ -82,6 +82,12 @@ typedef struct vh_config {
  * error grows with |row mean| / row sigma; for activations with a large common-mode offset choose VH_FLAG_LN_FOLD_OFF. */
 #define VH_FLAG_LN_FOLD_OFF 1 /* always run the stand-alone LayerNorm kernel                */
 #define VH_FLAG_LN_FOLD_ON 2  /* fold where the shapes allow it (the default, stated explicitly) */
+/* Weight-only e4m3 (16-bit dtypes only): the q, k, v, out-projection, fc1 and fc2 matrices are quantised to OCP e4m3
+ * with one fp32 scale per output channel when the weights are loaded and dequantised again before the 16-bit
+ * preparation, so the GEMMs multiply 16-bit activations with e4m3-valued weights (SURVEY.md section 7 option (a); the
+ * other reading of "fp8", both operands e4m3 on the scaled-MFMA path, is VH_DTYPE_FP8).  Throughput is that of the
+ * 16-bit dtype: at batch 512 the weights are 0.3 % of a forward's HBM traffic, which is all a 1-byte copy would save. */
+#define VH_FLAG_W8_E4M3 4
 
 typedef struct vh_ctx vh_ctx; /* opaque ViT context (device, stream, weights, workspace) */
 typedef struct vh_mlp vh_mlp; /* opaque MLP-mode context (the reference's real semantics)  */

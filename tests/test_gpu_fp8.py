@@ -205,6 +205,87 @@ def test_logits_track_the_fp8_emulation_and_the_fp32_forward(name, batch):
     assert e_gpu32 <= 0.25                            # sanity bound in the max-norm
 
 
+def test_full_size_config_5_vit_base_fp8_batch_512_properties():
+    # BASELINE.json config 5 at its FULL size: ViT-B/16, e4m3 GEMM operands, 512 images.  fp8 is outside the north
+    # star's tolerance by construction, so the parity statement is the one of the small fp8 cases (the GPU follows the
+    # oracle's e4m3 emulation of the same data flow as closely as that emulation follows fp32), made on rows of the
+    # FULL-size run, next to the size-independent properties: determinism, sub-batch and permutation bit-exactness.
+    cfg = S.CONFIGS["vit_base"]
+    B = 512
+    ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=B)
+    ctx.init_weights_seeded(0)
+    blob = ctx.export_weights()
+    din = vithip.DeviceBuffer(B * 224 * 224 * 3 * 4)
+    dout = vithip.DeviceBuffer(B * cfg["classes"] * 4)
+    ctx.fill_input_seeded(1, B, din.ptr)
+    ctx.forward_device(din.ptr, B, dout.ptr)
+    full = dout.to_numpy(np.float32, (B, cfg["classes"]))
+    assert np.isfinite(full).all()
+    ctx.forward_device(din.ptr, B, dout.ptr)
+    assert np.array_equal(dout.to_numpy(np.float32, (B, cfg["classes"])), full)
+    images = din.to_numpy(np.float32, (B, 224, 224, 3))
+    for lo, hi in ((0, 5), (255, 258), (511, 512)):
+        assert np.array_equal(ctx.forward(images[lo:hi]), full[lo:hi]), (lo, hi)
+    perm = np.array([400, 9, 511, 0, 77])
+    assert np.array_equal(ctx.forward(images[perm]), full[perm])
+    ref32 = O.vit_forward(cfg, blob, images[:4])
+    emu = O.vit_forward(cfg, blob, images[:4], fp8=True)
+    rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    r_emu32, r_gpu32, r_gpuemu = rms(emu, ref32), rms(full[:4], ref32), rms(full[:4], emu)
+    print(f"\n[full size] vit_base b512 fp8: rows 0-3 rms emu-fp32 {r_emu32:.3e} gpu-fp32 {r_gpu32:.3e} gpu-emu {r_gpuemu:.3e}; "
+          f"max-norm gpu-fp32 {rel(full[:4], ref32):.3e}")
+    assert r_gpu32 <= 1.5 * r_emu32 + 1e-3 and r_gpuemu <= 1.5 * r_emu32 + 1e-3
+    ctx.close()
+
+
+def weight_only_e4m3_blob(cfg, blob):
+    """The blob whose q/k/v/o/fc1/fc2 matrices went through the oracle's e4m3 row quantiser and back (fp32 values)."""
+    out = blob.copy()
+    off = 64
+    for name, shape, *_ in S.tensor_table(cfg):
+        n = int(np.prod(shape))
+        if name.endswith(".weight") and name.split(".")[1] in ("q", "k", "v", "o", "fc1", "fc2"):
+            w = out[off:off + 4 * n].view(np.float32).reshape(shape)
+            _, wq, sc = O.quantize_rows(w)
+            w[...] = wq * sc[:, None]
+        off += 4 * n
+    return out
+
+
+@pytest.mark.parametrize("dt,name", [(vithip.DTYPE_FP16, "fp16"), (vithip.DTYPE_BF16, "bf16")])
+def test_weight_only_e4m3_is_the_16_bit_forward_of_the_quantised_model(dt, name):
+    # SURVEY.md section 7 option (a): e4m3 WEIGHTS (one scale per output channel), 16-bit activations, next to option
+    # (b) = VH_DTYPE_FP8 (both operands e4m3).  Kernel parity: the flag's forward equals the plain 16-bit forward of
+    # the model whose weights went through the quantiser on the host.  Accuracy price: both options against the fp32
+    # oracle of the ORIGINAL weights, same images.
+    cfg = S.CONFIGS["vit_base"]
+    batch = 4
+    blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, batch)
+    ref32 = O.vit_forward(cfg, blob, images)
+    blob_q = weight_only_e4m3_blob(cfg, blob)
+    ref_q = O.vit_forward(cfg, blob_q, images)
+    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=batch, flags=vithip.FLAG_W8_E4M3)
+    ctx.load_weights(blob)
+    got = ctx.forward(images)
+    ctx.close()
+    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=batch)
+    ctx.load_weights(blob_q)
+    host_quantised = ctx.forward(images)
+    ctx.close()
+    ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=batch)
+    ctx.load_weights(blob)
+    both = ctx.forward(images)
+    ctx.close()
+    assert np.array_equal(got, host_quantised)                  # device quantiser == oracle quantiser, bit for bit
+    e_kernel, e_a, e_b = rel(got, ref_q), rel(got, ref32), rel(both, ref32)
+    print(f"\n[fp8 options] vit_base b{batch} {name}: (a) weight-only e4m3 vs its own fp32 model {e_kernel:.3e}, "
+          f"vs the original fp32 model {e_a:.3e}; (b) both operands e4m3 vs the original fp32 model {e_b:.3e}")
+    assert e_kernel <= (1e-3 if dt == vithip.DTYPE_FP16 else 1e-2)
+    assert e_a < e_b
+    with pytest.raises(vithip.VhError):
+        vithip.VitContext(cfg, dtype=FP8, max_batch=1, flags=vithip.FLAG_W8_E4M3)
+
+
 def test_fp8_is_deterministic_batch_independent_and_rejects_bad_dims():
     cfg = S.CONFIGS["vit_q8"]
     ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=5)

@@ -232,6 +232,44 @@ def test_full_size_batch_512_properties():
     ctx.close()
 
 
+def test_full_size_config_4_vit_large_384_fp16_batch_256_properties():
+    # BASELINE.json config 4 at its FULL size: ViT-L/16 at 384x384 (577 tokens, 24 layers), fp16, 256 images = 147 712
+    # token rows, 453 MB of input.  Size-independent properties as for config 2: sub-batches run alone (from both ends and
+    # the middle) reproduce their rows bit for bit, a permutation of images permutes the logits, the run is
+    # deterministic -- plus two rows against the oracle AT THE NORTH STAR'S TOLERANCE (fp16).
+    import ctypes as C
+    cfg = S.CONFIGS["vit_large_384"]
+    B, per = 256, 384 * 384 * 3
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=B)
+    ctx.init_weights_seeded(0)
+    blob = ctx.export_weights()
+    din = vithip.DeviceBuffer(B * per * 4)
+    dout = vithip.DeviceBuffer(B * cfg["classes"] * 4)
+    ctx.fill_input_seeded(1, B, din.ptr)
+    ctx.forward_device(din.ptr, B, dout.ptr)
+    full = dout.to_numpy(np.float32, (B, cfg["classes"]))
+    assert np.isfinite(full).all()
+    ctx.forward_device(din.ptr, B, dout.ptr)
+    assert np.array_equal(dout.to_numpy(np.float32, (B, cfg["classes"])), full)      # deterministic
+
+    def rows(lo, hi):
+        imgs = np.empty((hi - lo, 384, 384, 3), np.float32)
+        assert vithip.lib().vh_memcpy_d2h(0, imgs.ctypes.data, C.c_void_p(din.ptr + lo * per * 4), imgs.nbytes) == 0
+        return imgs
+
+    for lo, hi in ((0, 3), (127, 130), (255, 256)):
+        assert np.array_equal(ctx.forward(rows(lo, hi)), full[lo:hi]), (lo, hi)
+    perm = [200, 3, 255, 0]
+    assert np.array_equal(ctx.forward(np.concatenate([rows(i, i + 1) for i in perm])), full[perm])
+    first = rows(0, 2)
+    assert np.array_equal(first, S.make_images(cfg, 1, 2))                            # device generator == numpy generator
+    ref = O.vit_forward(cfg, blob, first)
+    e = rel(full[:2], ref)
+    print(f"\n[full size] vit_large_384 b256 fp16: rows 0-1 vs oracle {e:.3e}")
+    assert e <= NORTH_STAR, e
+    ctx.close()
+
+
 def test_batch_4096_crosses_the_2_to_31_element_mark():
     # BASELINE config 3's global batch on ONE device: 806 912 token rows; the MLP hidden tensor has 2.48e9 elements,
     # so every row * width product in the kernels must be 64-bit.  Checked through batch independence: images from

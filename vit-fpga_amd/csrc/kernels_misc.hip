@@ -197,6 +197,38 @@ hipError_t launch_quantize_rows(const float* w, int rows, int cols, float post, 
     return hipGetLastError();
 }
 
+// Weight-only e4m3 (VH_FLAG_W8_E4M3): out[r, :] = decode(quantise(w[r, :])) * s0 with the quantiser above -- the values
+// a GEMM would see if the weight matrix were stored as e4m3 bytes + one scale per output channel and dequantised on its
+// way to the matrix core.  The 16-bit weight preparation (cast / q|k|v packing / LayerNorm fold) then runs on `out`.
+__global__ void __launch_bounds__(256)
+fake_quant_rows_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const f32x4* wr = (const f32x4*)(w + (int64_t)r * cols);
+    const int n4 = cols >> 2;
+    float amax = 0.f;
+    for (int c = lane; c < n4; c += 64) {
+        const f32x4 v = wr[c];
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float s0 = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    f32x4* orow = (f32x4*)(out + (int64_t)r * cols);
+    for (int c = lane; c < n4; c += 64) {
+        const f32x4 v = wr[c];
+        const int q = (int)pack4_e4m3(__fdiv_rn(v[0], s0), __fdiv_rn(v[1], s0), __fdiv_rn(v[2], s0), __fdiv_rn(v[3], s0));
+        orow[c] = f32x4{__builtin_amdgcn_cvt_f32_fp8(q, 0) * s0, __builtin_amdgcn_cvt_f32_fp8(q, 1) * s0,
+                        __builtin_amdgcn_cvt_f32_fp8(q, 2) * s0, __builtin_amdgcn_cvt_f32_fp8(q, 3) * s0};
+    }
+}
+hipError_t launch_fake_quant_rows(const float* w, int rows, int cols, float* out, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || (cols & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fake_quant_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, w, rows, cols, out);
+    return hipGetLastError();
+}
+
 // ---- weight re-layout ---------------------------------------------------------------------------
 // Wqkv[3D, D] = [q * q_scale ; k ; v] (16-bit), bqkv[3D] = [bq * q_scale ; bk ; bv] (fp32).
 // q_scale = 64^-1/2 = 0.125 is a power of two, so folding it into the weights is exact.

@@ -60,6 +60,8 @@ hipError_t launch_fill(float* out, int64_t n, uint64_t seed, uint32_t tensor_id,
                        float sigma, float offset, hipStream_t stream);
 // fp8 weight quantisation: w fp32 [rows, cols] -> e4m3 [rows, cols] with scale[r] = post * amax_r / 448 (amax 0 -> post),
 // q = rne_e4m3(w / (amax_r / 448)); `post` folds a constant factor into the scale (the q rows' softmax scale)
+// out = decode(e4m3(w / s0)) * s0 per row, s0 = amax_row / 448: the values of a weight-only e4m3 matrix (VH_FLAG_W8_E4M3)
+hipError_t launch_fake_quant_rows(const float* w, int rows, int cols, float* out, hipStream_t stream);
 hipError_t launch_quantize_rows(const float* w, int rows, int cols, float post, void* w8, float* scale, hipStream_t stream);
 // weight preparation (fp32 canonical tensors -> compute layout)
 hipError_t launch_pack_qkv(const float* qw, const float* qb, const float* kw, const float* kb,

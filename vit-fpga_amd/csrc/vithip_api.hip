@@ -121,7 +121,9 @@ const char* check_config(const vh_config& c) {
     if (c.dtype == VH_DTYPE_FP8 && (c.dim % 128 || c.mlp_dim % 128)) return "VH_DTYPE_FP8 needs dim and mlp_dim to be multiples of 128";
     if (c.max_batch <= 0) return "max_batch must be positive";
     if (!(c.ln_eps > 0.f)) return "ln_eps must be positive";
-    if (c.flags & ~(VH_FLAG_LN_FOLD_OFF | VH_FLAG_LN_FOLD_ON)) return "unknown bits in flags";
+    if (c.flags & ~(VH_FLAG_LN_FOLD_OFF | VH_FLAG_LN_FOLD_ON | VH_FLAG_W8_E4M3)) return "unknown bits in flags";
+    if ((c.flags & VH_FLAG_W8_E4M3) && c.dtype == VH_DTYPE_FP8) return "flags: VH_FLAG_W8_E4M3 is for the 16-bit dtypes (VH_DTYPE_FP8 quantises both operands)";
+    if ((c.flags & VH_FLAG_W8_E4M3) && (c.dim % 4 || c.mlp_dim % 4)) return "flags: VH_FLAG_W8_E4M3 needs dim and mlp_dim multiples of 4";
     if ((c.flags & VH_FLAG_LN_FOLD_OFF) && (c.flags & VH_FLAG_LN_FOLD_ON)) return "flags: VH_FLAG_LN_FOLD_OFF and VH_FLAG_LN_FOLD_ON exclude each other";
     // bounds that keep every size computation below far from overflow (and a crafted file header from driving an
     // allocation: vh_blob_file_config feeds this function)
@@ -276,26 +278,50 @@ int prepare_weights(vh_ctx* c) {
         HIPCHK(&c->err, launch_quantize_rows(P + o.f1w, M, D, 1.0f, c->w1_16[l], c->s1[l], s));
         HIPCHK(&c->err, launch_quantize_rows(P + o.f2w, D, M, 1.0f, c->w2_16[l], c->s2[l], s));
     }
+    // VH_FLAG_W8_E4M3: the six matrices of a layer pass through the e4m3 quantiser (one scale per output channel) and back
+    // before the 16-bit preparation -- weight-only fp8 with dequantisation at load (SURVEY.md section 7 option (a))
+    float* w8tmp = nullptr;
+    const size_t dd1 = (size_t)D * D, md1 = (size_t)M * D;
+    if (!c->fp8 && (f.flags & VH_FLAG_W8_E4M3)) { HIPCHK(&c->err, hipMalloc((void**)&w8tmp, (4 * dd1 + 2 * md1) * sizeof(float))); }
     for (int l = 0; l < f.layers && !c->fp8; ++l) {
-        const LayerOff& o = L.layer[l];
+        LayerOff o = L.layer[l];
+        const float* P = c->params;
+        if (w8tmp) {
+            const size_t src[6] = {o.qw, o.kw, o.vw, o.ow, o.f1w, o.f2w};
+            const int rows[6] = {D, D, D, D, M, D}, cols[6] = {D, D, D, D, D, M};
+            size_t at = 0;
+            for (int i = 0; i < 6; ++i) {
+                if (hipError_t e = launch_fake_quant_rows(c->params + src[i], rows[i], cols[i], w8tmp + at, s); e != hipSuccess) {
+                    hipFree(w8tmp);
+                    return fail(&c->err, VH_ERR_HIP, "weight-only e4m3 quantiser: %s", hipGetErrorString(e));
+                }
+                at += (size_t)rows[i] * cols[i];
+            }
+            // the matrix offsets now point into w8tmp (relative to P = w8tmp - 0): rebase through pointer arithmetic
+            P = w8tmp;
+            o.qw = 0; o.kw = dd1; o.vw = 2 * dd1; o.ow = 3 * dd1; o.f1w = 4 * dd1; o.f2w = 4 * dd1 + md1;
+        }
+        const float* B = c->params;   // biases and LayerNorm parameters stay where they are
         if (c->ln_fold) {
             // W' = gamma o W (q rows also carry the softmax scale kAttnQScale), c = row sums of W', d = beta.W + b
             float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
             char* wq = (char*)c->wqkv16[l];
             const size_t dd2 = (size_t)D * D * 2;
-            HIPCHK(&c->err, launch_fold_ln(P + o.qw, P + o.qb, P + o.ln1w, P + o.ln1b, D, D, kAttnQScale, wq, cd, cd + 3 * D, f.dtype, s));
-            HIPCHK(&c->err, launch_fold_ln(P + o.kw, P + o.kb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + dd2, cd + D, cd + 4 * D, f.dtype, s));
-            HIPCHK(&c->err, launch_fold_ln(P + o.vw, P + o.vb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + 2 * dd2, cd + 2 * D, cd + 5 * D, f.dtype, s));
-            HIPCHK(&c->err, launch_fold_ln(P + o.f1w, P + o.f1b, P + o.ln2w, P + o.ln2b, M, D, 1.0f, c->w1_16[l], cd + 6 * D, cd + 6 * D + M, f.dtype, s));
+            HIPCHK(&c->err, launch_fold_ln(P + o.qw, B + o.qb, B + o.ln1w, B + o.ln1b, D, D, kAttnQScale, wq, cd, cd + 3 * D, f.dtype, s));
+            HIPCHK(&c->err, launch_fold_ln(P + o.kw, B + o.kb, B + o.ln1w, B + o.ln1b, D, D, 1.0f, wq + dd2, cd + D, cd + 4 * D, f.dtype, s));
+            HIPCHK(&c->err, launch_fold_ln(P + o.vw, B + o.vb, B + o.ln1w, B + o.ln1b, D, D, 1.0f, wq + 2 * dd2, cd + 2 * D, cd + 5 * D, f.dtype, s));
+            HIPCHK(&c->err, launch_fold_ln(P + o.f1w, B + o.f1b, B + o.ln2w, B + o.ln2b, M, D, 1.0f, c->w1_16[l], cd + 6 * D, cd + 6 * D + M, f.dtype, s));
         } else {
-            HIPCHK(&c->err, launch_pack_qkv(P + o.qw, P + o.qb, P + o.kw, P + o.kb, P + o.vw, P + o.vb, D, kAttnQScale,
+            HIPCHK(&c->err, launch_pack_qkv(P + o.qw, B + o.qb, P + o.kw, B + o.kb, P + o.vw, B + o.vb, D, kAttnQScale,
                                             c->wqkv16[l], c->bqkv + (size_t)l * 3 * D, f.dtype, s));
             HIPCHK(&c->err, launch_cast(P + o.f1w, c->w1_16[l], (int64_t)M * D, f.dtype, s));
         }
         HIPCHK(&c->err, launch_cast(P + o.ow, c->wo16[l], (int64_t)D * D, f.dtype, s));
         HIPCHK(&c->err, launch_cast(P + o.f2w, c->w2_16[l], (int64_t)D * M, f.dtype, s));
+        if (w8tmp) { HIPCHK(&c->err, hipStreamSynchronize(s)); }   // the scratch is reused by the next layer
     }
     HIPCHK(&c->err, hipStreamSynchronize(s));
+    if (w8tmp) hipFree(w8tmp);
     c->weights_ready = true;
     return VH_OK;
 }
