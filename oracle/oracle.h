@@ -59,6 +59,9 @@ int oracle_vit_forward(const oracle_vit_config* c, const void* blob, const float
  * device must be as close to the fp32 forward as this emulation is (tests/test_gpu_fp8.py). */
 int oracle_vit_forward_fp8(const oracle_vit_config* c, const void* blob, const float* in_nhwc,
                            int batch, float* logits, float* hidden, int n_layers_run, int threads);
+/* the same with the LayerNorm folded into q|k|v and fc1 (e4m3 copy of the RAW residual rows as the operand) */
+int oracle_vit_forward_fp8_folded(const oracle_vit_config* c, const void* blob, const float* in_nhwc,
+                           int batch, float* logits, float* hidden, int n_layers_run, int threads);
 /* The fp32 forward with the device's 16-bit ROUNDING POINTS emulated one by one (dtype 0 = bf16, 1 = fp16; mask bits:
  * 1 patch and per-layer weights, 2 LayerNorm output, 4 q|k|v, 8 softmax probabilities, 16 attention output, 32 GELU
  * output, 64 patch matrix, 128 final-LN'd CLS rows, 512 head weights, 256 LayerNorm folded into q|k|v / fc1 instead of bit 2).  Accumulation, residual

@@ -357,6 +357,48 @@ static void linear_scaled(const float* a, const float* wq, const float* scale, c
         for (int n = 0; n < N; ++n) out[m * N + n] = out[m * N + n] * scale[n] + bias[n];
 }
 
+/* VH_DTYPE_FP8 with the LayerNorm FOLDED into the following GEMM (vithip_api.hip prepare_weights / launch_fold_ln_f8):
+ * operand = e4m3 of the RAW residual rows; W' = gamma o W through the row quantiser (decoded values wq, scales sc);
+ * out[m,n] = rstd_m * (sc_n * sum_k x8[m,k] wq[n,k] - mean_m * c_n) + d_n with c_n = sc_n * sum_k wq[n,k] and
+ * d_n = sum_k beta_k W[n,k] + b_n; (mean, rstd) from the fp32 rows.  `x8` is scratch for rows * D floats. */
+static void ln_linear_f8_folded(const float* x, int64_t rows, int D, const float* lnw, const float* lnb, const float* W,
+                                const float* B, int N, float eps, float* x8, float* out) {
+    float* wg = (float*)malloc(sizeof(float) * (size_t)N * D);
+    float* wq = (float*)malloc(sizeof(float) * (size_t)N * D);
+    float* sc = (float*)malloc(sizeof(float) * (size_t)N);
+    float* cd = (float*)malloc(sizeof(float) * (size_t)N * 2);
+    float* st = (float*)malloc(sizeof(float) * (size_t)rows * 2);
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < D; ++k) wg[(size_t)n * D + k] = lnw[k] * W[(size_t)n * D + k];
+    oracle_quantize_rows(wg, N, D, 1.0f, NULL, wq, sc);
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        double cs = 0.0, ds = 0.0;
+        for (int k = 0; k < D; ++k) { cs += wq[(size_t)n * D + k]; ds += (double)lnb[k] * W[(size_t)n * D + k]; }
+        cd[2 * n] = (float)(cs * sc[n]);
+        cd[2 * n + 1] = (float)(ds + B[n]);
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < rows; ++m) {
+        const float* xr = x + m * D;
+        double sum = 0.0, var = 0.0;
+        for (int k = 0; k < D; ++k) sum += xr[k];
+        const double mean = sum / D;
+        for (int k = 0; k < D; ++k) { const double d = xr[k] - mean; var += d * d; }
+        st[2 * m] = (float)mean;
+        st[2 * m + 1] = (float)(1.0 / sqrt(var / D + eps));
+    }
+    memcpy(x8, x, sizeof(float) * (size_t)rows * D);
+    oracle_quant_e4m3(x8, rows * D);
+    oracle_linear(x8, wq, NULL, out, rows, N, D);
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < rows; ++m)
+        for (int n = 0; n < N; ++n)
+            out[m * N + n] = st[2 * m + 1] * (out[m * N + n] * sc[n] - st[2 * m] * cd[2 * n]) + cd[2 * n + 1];
+    free(wg); free(wq); free(sc); free(cd); free(st);
+}
+
 /* emul16: 0 = plain fp32; else 1 + dtype (1 = bf16, 2 = fp16) with `mask` choosing WHICH tensors are rounded to that
  * 16-bit type on their way into a matrix product, i.e. where the device (vit-fpga_amd/csrc) holds an MFMA operand:
  *   1 weights (patch + per-layer matrices)   2 LayerNorm output   4 q|k|v   8 softmax probabilities   16 attention output
@@ -468,6 +510,25 @@ static int vit_forward_impl(const oracle_vit_config* c, const void* blob, const 
         memcpy(bqkv + D, kb, sizeof(float) * D);
         memcpy(bqkv + 2 * D, vb, sizeof(float) * D);
 
+        if (fp8 == 2) {
+            /* VH_DTYPE_FP8 with the folded LayerNorm (the default where dim and mlp_dim are multiples of 256) */
+            ln_linear_f8_folded(x, rows, D, ln1w, ln1b, wqkv, bqkv, 3 * D, c->ln_eps, y, qkv);
+            oracle_round_bf16(qkv, rows * 3 * D);
+            oracle_attention(qkv, batch, T, H, dh, att);
+            oracle_quant_e4m3(att, rows * D);
+            oracle_quantize_rows(ow, D, D, 1.0f, NULL, wq8, wsc);
+            linear_scaled(att, wq8, wsc, ob, y, rows, D, D);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < rows * D; ++i) x[i] += y[i];
+            ln_linear_f8_folded(x, rows, D, ln2w, ln2b, f1w, f1b, Mh, c->ln_eps, y, hid);
+            oracle_gelu(hid, rows * Mh);
+            oracle_quant_e4m3(hid, rows * Mh);
+            oracle_quantize_rows(f2w, D, Mh, 1.0f, NULL, wq8, wsc);
+            linear_scaled(hid, wq8, wsc, f2b, y, rows, D, Mh);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < rows * D; ++i) x[i] += y[i];
+            continue;
+        }
         if (fp8) {
             /* the device's VH_DTYPE_FP8 data flow: every GEMM operand is e4m3 (weights with a per-row scale,
              * activations unscaled), fp32 accumulation, qkv stored as bf16, fp32 residual stream */
@@ -617,4 +678,8 @@ int oracle_vit_forward_emul16(const oracle_vit_config* c, const void* blob, cons
 int oracle_vit_forward_fp8(const oracle_vit_config* c, const void* blob, const float* in,
                            int batch, float* logits, float* hidden, int n_layers_run, int threads) {
     return vit_forward_impl(c, blob, in, batch, logits, hidden, n_layers_run, threads, 1, 0, 0);
+}
+int oracle_vit_forward_fp8_folded(const oracle_vit_config* c, const void* blob, const float* in,
+                                  int batch, float* logits, float* hidden, int n_layers_run, int threads) {
+    return vit_forward_impl(c, blob, in, batch, logits, hidden, n_layers_run, threads, 2, 0, 0);
 }

@@ -49,6 +49,8 @@ def lib():
                                          C.c_int, C.c_int]
         L.oracle_vit_forward_fp8.restype = C.c_int
         L.oracle_vit_forward_fp8.argtypes = L.oracle_vit_forward.argtypes
+        L.oracle_vit_forward_fp8_folded.restype = C.c_int
+        L.oracle_vit_forward_fp8_folded.argtypes = L.oracle_vit_forward.argtypes
         L.oracle_e4m3_from_float.restype = C.c_uint8
         L.oracle_e4m3_from_float.argtypes = [C.c_float]
         L.oracle_e4m3_to_float.restype = C.c_float
@@ -110,14 +112,15 @@ def make_blob(cfg, seed, ln_eps=1e-6):
 
 
 def vit_forward(cfg, blob, images, n_layers=-1, threads=0, want_hidden=False, ln_eps=1e-6, fp8=False):
-    """fp8=True: the emulation of the device's VH_DTYPE_FP8 data flow (oracle.h, oracle_vit_forward_fp8)."""
+    """fp8=True: the emulation of the device's VH_DTYPE_FP8 data flow (oracle.h, oracle_vit_forward_fp8);
+    fp8="folded": the same with the LayerNorm folded into q|k|v and fc1 (oracle_vit_forward_fp8_folded)."""
     c = cfg_struct(cfg, ln_eps)
     images = _f32(images)
     batch = images.shape[0]
     logits = np.empty((batch, cfg["classes"]), dtype=np.float32)
     g = cfg["image_size"] // cfg["patch_size"]
     hidden = np.empty((batch * (1 + g * g), cfg["dim"]), dtype=np.float32) if want_hidden else None
-    fn = lib().oracle_vit_forward_fp8 if fp8 else lib().oracle_vit_forward
+    fn = lib().oracle_vit_forward_fp8_folded if fp8 == "folded" else (lib().oracle_vit_forward_fp8 if fp8 else lib().oracle_vit_forward)
     rc = fn(C.byref(c), blob.ctypes.data, _fp(images), batch, _fp(logits),
             _fp(hidden) if want_hidden else None, n_layers, threads)
     assert rc == 0, rc

@@ -75,3 +75,18 @@ def test_row_quantiser_scales_and_fp8_forward_is_close_to_fp32_forward():
     q = O.vit_forward(cfg, blob, images, fp8=True)
     err = np.abs(q - ref).max() / np.abs(ref).max()
     assert 1e-4 < err < 0.15, err
+
+
+def test_folded_fp8_emulation_is_the_same_model_with_another_rounding_pattern():
+    # oracle_vit_forward_fp8_folded: the LayerNorm folded into q|k|v and fc1 (e4m3 copy of the RAW rows as the operand).
+    # Without e4m3 rounding the two data flows are the same function; with it they differ by fp8 noise only: the folded
+    # emulation is as close to fp32 as the plain one (within a factor 1.5), and not identical to it.
+    cfg = S.CONFIGS["vit_q8"]
+    blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, 2)
+    ref = O.vit_forward(cfg, blob, images)
+    plain = O.vit_forward(cfg, blob, images, fp8=True)
+    folded = O.vit_forward(cfg, blob, images, fp8="folded")
+    rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    r_plain, r_folded = rms(plain, ref), rms(folded, ref)
+    assert not np.array_equal(plain, folded)
+    assert 1e-4 < r_folded < 1.5 * r_plain + 1e-3, (r_plain, r_folded)

@@ -182,13 +182,17 @@ def test_layernorm_and_attention_write_e4m3():
     assert np.all(np.abs(got - ref) <= 2.0 ** -4 * np.abs(ref) + 1.2e-2 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("name,batch", [("vit_q8", 4), ("vit_base", 2)])
-def test_logits_track_the_fp8_emulation_and_the_fp32_forward(name, batch):
+@pytest.mark.parametrize("name,batch,flags,folded", [("vit_q8", 4, 0, False), ("vit_base", 2, 0, True),
+                                                     ("vit_base", 2, vithip.FLAG_LN_FOLD_OFF, False)])
+def test_logits_track_the_fp8_emulation_and_the_fp32_forward(name, batch, flags, folded):
+    # vit_q8 (mlp_dim 640) cannot fold its LayerNorms; ViT-B folds them by default (e4m3 copy of the RAW residual rows as
+    # the operand of q|k|v and fc1, oracle_vit_forward_fp8_folded) and runs the stand-alone LayerNorm on request
     cfg = S.CONFIGS[name]
     blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, batch)
     ref32 = O.vit_forward(cfg, blob, images)
-    emu = O.vit_forward(cfg, blob, images, fp8=True)
-    ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=batch)
+    emu = O.vit_forward(cfg, blob, images, fp8="folded" if folded else True)
+    ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=batch, flags=flags)
+    assert ctx.ln_fold() == folded
     ctx.load_weights(blob)
     got = ctx.forward(images)
     ctx.close()
@@ -197,7 +201,7 @@ def test_logits_track_the_fp8_emulation_and_the_fp32_forward(name, batch):
     rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
     r_emu32, r_gpu32, r_gpuemu = rms(emu, ref32), rms(got, ref32), rms(got, emu)
     top1 = float((got.argmax(1) == ref32.argmax(1)).mean())
-    print(f"\n[fp8] {name} b{batch}: max-norm emu-fp32 {e_emu32:.3e} gpu-fp32 {e_gpu32:.3e} gpu-emu {e_gpuemu:.3e}; "
+    print(f"\n[fp8] {name} b{batch} {'folded LN' if folded else 'stand-alone LN'}: max-norm emu-fp32 {e_emu32:.3e} gpu-fp32 {e_gpu32:.3e} gpu-emu {e_gpuemu:.3e}; "
           f"rms emu-fp32 {r_emu32:.3e} gpu-fp32 {r_gpu32:.3e} gpu-emu {r_gpuemu:.3e}; top1 agree {top1:.2f}")
     assert np.isfinite(got).all()
     assert r_gpu32 <= 1.5 * r_emu32 + 1e-3          # as close to the truth as the emulated data flow is
@@ -229,7 +233,8 @@ def test_full_size_config_5_vit_base_fp8_batch_512_properties():
     perm = np.array([400, 9, 511, 0, 77])
     assert np.array_equal(ctx.forward(images[perm]), full[perm])
     ref32 = O.vit_forward(cfg, blob, images[:4])
-    emu = O.vit_forward(cfg, blob, images[:4], fp8=True)
+    assert ctx.ln_fold()
+    emu = O.vit_forward(cfg, blob, images[:4], fp8="folded")
     rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
     r_emu32, r_gpu32, r_gpuemu = rms(emu, ref32), rms(full[:4], ref32), rms(full[:4], emu)
     print(f"\n[full size] vit_base b512 fp8: rows 0-3 rms emu-fp32 {r_emu32:.3e} gpu-fp32 {r_gpu32:.3e} gpu-emu {r_gpuemu:.3e}; "

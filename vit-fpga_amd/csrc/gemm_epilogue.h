@@ -431,19 +431,32 @@ template <int EPI, int MI, int NI, int SMI, bool MFULL = false, typename Hook = 
 __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w, int lane,
                                                bool n_full, char* smem, int wave, const Hook& hook = Hook()) {
     static_assert(NI == 4 && MI % SMI == 0, "64-column wave tile");
-    static_assert(EPI == VH_EPI_BIAS || EPI == VH_EPI_BIAS_GELU, "8-bit output: bias or bias+GELU");
+    static_assert(EPI == VH_EPI_BIAS || EPI == VH_EPI_BIAS_GELU || EPI == VH_EPI_LNFOLD_GELU, "8-bit output: bias, bias+GELU or LN-fold+GELU");
     const int M = e.M, N = e.N;
     const int frow = lane & 15, fq = lane >> 4;
     uint8_t* const out = (uint8_t*)e.out;
-    auto value = [&](const f32x4& a, const f32x4& b) {
-        f32x4 v = a + b;
-        if constexpr (EPI == VH_EPI_BIAS_GELU) v = gelu_poly4(v);
+    // LNFOLD_GELU (fp8 path with the folded LayerNorm): v = gelu(rstd_m * (acc - mean_m * c_n) + d_n), as epi_value16
+    auto value = [&](const f32x4& a, const f32x4& b, const f32x4& cq = f32x4{0.f, 0.f, 0.f, 0.f}, float mean_rstd = 0.f, float rstd = 0.f) {
+        f32x4 v = epi_value16<EPI>(a, b, cq, mean_rstd, rstd);
         return pack4_e4m3(v[0], v[1], v[2], v[3]);
     };
-    if (n_full || !is_no_hook<Hook>::value) {   // with a hook (persistent GEMM): staged form only, full tiles guaranteed
-        f32x4 bv[NI];
+    if (n_full || !is_no_hook<Hook>::value || epi_is_lnfold(EPI)) {   // with a hook (persistent GEMM) / LN fold: staged form only, N % tile == 0 guaranteed
+        f32x4 bv[NI], cv[NI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
+        for (int ni = 0; ni < NI; ++ni) {
+            bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
+            if constexpr (epi_is_lnfold(EPI)) cv[ni] = *(const f32x4*)(e.aux + n_w + ni * 16 + fq * 4);
+            else cv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float2 lnst[epi_is_lnfold(EPI) ? MI : 1];
+        if constexpr (epi_is_lnfold(EPI)) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int m = m_w + mi * 16 + frow;
+                m = m < M ? m : M - 1;
+                lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
+            }
+        }
         run_hook(hook);
         char* sw = smem + wave * (SMI * 16 * 128);
         const int rr = lane >> 2, pc = lane & 3;
@@ -453,8 +466,14 @@ __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const
             for (int mi = 0; mi < SMI; ++mi) {
                 const int r = mi * 16 + frow;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    *(uint32_t*)(sw + r * 64 + ((ni ^ ((r >> 1) & 3)) << 4) + fq * 4) = value(acc[h * SMI + mi][ni], bv[ni]);
+                for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (epi_is_lnfold(EPI)) {
+                        const float2 st = lnst[h * SMI + mi];
+                        *(uint32_t*)(sw + r * 64 + ((ni ^ ((r >> 1) & 3)) << 4) + fq * 4) = value(acc[h * SMI + mi][ni], bv[ni], cv[ni], st.x * st.y, st.y);
+                    } else {
+                        *(uint32_t*)(sw + r * 64 + ((ni ^ ((r >> 1) & 3)) << 4) + fq * 4) = value(acc[h * SMI + mi][ni], bv[ni]);
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < SMI; ++i) {
@@ -467,7 +486,7 @@ __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const
         }
         return;
     }
-    if constexpr (is_no_hook<Hook>::value) {
+    if constexpr (is_no_hook<Hook>::value && !epi_is_lnfold(EPI)) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n = n_w + ni * 16 + fq * 4;

@@ -105,7 +105,8 @@ __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                   const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
-                  void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn VH_STAMP_PARAM) {
+                  void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn,
+                  const float* __restrict__ wscale VH_STAMP_PARAM) {
     using vec8 = typename T::vec8;
 #ifdef VH_DIAG_STAMPS
     // the iteration whose stamps are kept: the workgroup's only tile, or the SECOND tile of a persistent workgroup
@@ -381,7 +382,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         int lane_e = lane;
         if constexpr (PERSIST) asm volatile("" : "+v"(lane_e));
         if constexpr (F8) {
-            // per-output-channel weight scale (`aux`): the lane's 4 consecutive columns of column block ni.  The product is
+            // per-output-channel weight scale (`wscale`): the lane's 4 consecutive columns of column block ni.  The product is
             // rounded on its own (no contraction with the epilogue's "+ bias" into an fma): every form of the kernel then
             // produces the same bits, whatever the compiler's inlining context makes of the two statements.
 #pragma clang fp contract(off)
@@ -389,7 +390,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int n = n_w + ni * 16 + fq_e * 4;
-                const f32x4 ws = n < N ? *(const f32x4*)(aux + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 ws = n < N ? *(const f32x4*)(wscale + n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = acc[mi][ni] * ws;
             }
@@ -401,13 +402,18 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // (fp32 results: 16 rows x 256 B per pass, so that the 8 waves' slices fit the 32 KiB behind the stages)
             constexpr int SLICE = VH_PP_SMI * 16 * 128;
             static_assert(VH_PP_SMI == 2, "staging region of the persistent form: 8 waves x 4 KiB");
-            if constexpr (F8 && EPI == VH_EPI_BIAS_GELU)
+            // fp8 operands: GELU results leave as e4m3 (the next GEMM's A operand); RESID_LN writes an e4m3 copy of the rows
+            if constexpr (F8 && epi_has_gelu(EPI))
                 gemm_epilogue8<EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, true, stage_epi, wave);
+            else if constexpr (F8 && EPI == VH_EPI_RESID_LN)
+                gemm_epilogue_staged<E4M3, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
             else
                 gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
         } else {
-            if constexpr (F8 && EPI == VH_EPI_BIAS_GELU)
+            if constexpr (F8 && epi_has_gelu(EPI))
                 gemm_epilogue8<EPI, MI, NI, VH_PP_SMI>(acc, e, m_w, n_w, lane_e, n_full, stage_epi, wave);
+            else if constexpr (F8 && EPI == VH_EPI_RESID_LN)
+                gemm_epilogue<E4M3, EPI, MI, NI, 4, false>(acc, e, m_w, n_w, lane_e, n_full, m_full, stage_epi, wave);
             else
                 gemm_epilogue<T, EPI, MI, NI, (epi_is_16bit(EPI) ? VH_PP_SMI : 4), false>(acc, e, m_w, n_w, lane_e, n_full, m_full, stage_epi, wave);   // fp32 forms: 32 rows per pass
         }
@@ -473,7 +479,8 @@ static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int ti
     static int lds_done[kMaxDevices] = {0};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
-                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n)
+                       tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n),
+                       F8 ? (g.wscale ? g.wscale : g.aux) : (const float*)nullptr
                        VH_STAMP_ARG(g, EPI, F8, grid, PERSIST ? 6 : (AST == 3 ? 7 : 5)));
     return hipGetLastError();
 }
@@ -543,6 +550,10 @@ hipError_t launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
         case VH_EPI_BIAS_GELU: return launch_pp<BF16, VH_EPI_BIAS_GELU, true>(g, mode, s);
         case VH_EPI_BIAS_RESID: return launch_pp<BF16, VH_EPI_BIAS_RESID, true>(g, mode, s);
         case VH_EPI_BIAS_F32: return launch_pp<BF16, VH_EPI_BIAS_F32, true>(g, mode, s);
+        // folded LayerNorm on e4m3 operands: `aux` = c_n, `wscale` = the weight scales, `stats` = (mean, rstd) per row
+        case VH_EPI_LNFOLD: return g.wscale && g.stats && g.aux ? launch_pp<BF16, VH_EPI_LNFOLD, true>(g, mode, s) : hipErrorInvalidValue;
+        case VH_EPI_LNFOLD_GELU: return g.wscale && g.stats && g.aux && g.N % 256 == 0 ? launch_pp<BF16, VH_EPI_LNFOLD_GELU, true>(g, mode, s) : hipErrorInvalidValue;
+        case VH_EPI_RESID_LN: return g.out16 && g.partials && g.N % 256 == 0 ? launch_pp<BF16, VH_EPI_RESID_LN, true>(g, mode, s) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,6 +1,8 @@
 // kernels_misc.hip — the HBM-bound pieces around the GEMMs (gfx950): LayerNorm, patch
 // gather (im2col + cast), CLS-row initialisation, casts, weight re-layout, the synthetic-data
 // generator and the fp32 dense layer of MLP mode.  All of them move 16 bytes per lane.
+#include <type_traits>
+
 #include "vh_kernels.h"
 
 namespace vh {
@@ -349,8 +351,10 @@ rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float e
             for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; var += d * d; }
             const typename T::vec4 hq = pack4<T>(v[i][0], v[i][1], v[i][2], v[i][3]);
             *(typename T::vec4*)(x16 + row * dim + 4 * c) = hq;
-            if (xlo) *(typename T::vec4*)(xlo + row * dim + 4 * c) = pack4<T>(v[i][0] - (float)hq[0], v[i][1] - (float)hq[1],
-                                                                           v[i][2] - (float)hq[2], v[i][3] - (float)hq[3]);
+            if constexpr (!std::is_same<T, E4M3>::value) {
+                if (xlo) *(typename T::vec4*)(xlo + row * dim + 4 * c) = pack4<T>(v[i][0] - (float)hq[0], v[i][1] - (float)hq[1],
+                                                                               v[i][2] - (float)hq[2], v[i][3] - (float)hq[3]);
+            }
         }
     }
 #pragma unroll
@@ -374,6 +378,7 @@ static hipError_t rowstats_t(const float* x, int64_t rows, int dim, float eps, v
 hipError_t launch_rowstats_cast(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, int dtype,
                                 hipStream_t s) {
     if (rows <= 0 || dim <= 0 || (dim & 3)) return hipErrorInvalidValue;
+    if (dtype == VH_DTYPE_FP8) return rowstats_t<E4M3>(x, rows, dim, eps, x16, stats, s);   // e4m3 copy of the raw rows (fp8 path, folded LN)
     return dtype == VH_DTYPE_BF16 ? rowstats_t<BF16>(x, rows, dim, eps, x16, stats, s)
                                   : rowstats_t<FP16>(x, rows, dim, eps, x16, stats, s);
 }
@@ -465,6 +470,54 @@ fold_ln_kernel(const float* __restrict__ w, const float* __restrict__ b, const f
     for (int o = 32; o > 0; o >>= 1) { cs += __shfl_xor(cs, o); ds += __shfl_xor(ds, o); }
     if (lane == 0) { c[n] = cs; d[n] = scale * (ds + b[n]); }
 }
+// The same fold for e4m3 weights (fp8 path): W'[n,:] = scale * gamma o W[n,:] goes through the row quantiser
+// (quantize_rows_kernel: s0 = amax / 448, bytes = rne_e4m3(W' / s0)); wscale[n] = s0; c[n] = s0 * sum_k decode(byte_k)
+// (the sum of what the scaled MFMA multiplies, so that mean * c cancels it exactly); d[n] as above.  dim % 4 == 0.
+__global__ void __launch_bounds__(256)
+fold_ln_f8_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+                  const float* __restrict__ beta, int rows, int dim, float scale, uint8_t* __restrict__ w8,
+                  float* __restrict__ wscale, float* __restrict__ c, float* __restrict__ d) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= rows) return;
+    const f32x4* wr = (const f32x4*)(w + (int64_t)n * dim);
+    const f32x4* gr = (const f32x4*)gamma;
+    const f32x4* br = (const f32x4*)beta;
+    const int n4 = dim >> 2;
+    float amax = 0.f, ds = 0.f;
+    for (int k = lane; k < n4; k += 64) {
+        const f32x4 wv = wr[k], g = gr[k], be = br[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            amax = fmaxf(amax, fabsf(scale * g[j] * wv[j]));
+            ds = fmaf(be[j], wv[j], ds);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, o)); ds += __shfl_xor(ds, o); }
+    const float s0 = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    uint32_t* orow = (uint32_t*)(w8 + (int64_t)n * dim);
+    float cs = 0.f;
+    for (int k = lane; k < n4; k += 64) {
+        const f32x4 wv = wr[k], g = gr[k];
+        const int q = (int)pack4_e4m3(__fdiv_rn(scale * g[0] * wv[0], s0), __fdiv_rn(scale * g[1] * wv[1], s0),
+                                      __fdiv_rn(scale * g[2] * wv[2], s0), __fdiv_rn(scale * g[3] * wv[3], s0));
+        orow[k] = (uint32_t)q;
+        cs += (__builtin_amdgcn_cvt_f32_fp8(q, 0) + __builtin_amdgcn_cvt_f32_fp8(q, 1)) +
+              (__builtin_amdgcn_cvt_f32_fp8(q, 2) + __builtin_amdgcn_cvt_f32_fp8(q, 3));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o);
+    if (lane == 0) { wscale[n] = s0; c[n] = s0 * cs; d[n] = scale * (ds + b[n]); }
+}
+hipError_t launch_fold_ln_f8(const float* w, const float* b, const float* gamma, const float* beta, int rows, int dim,
+                             float scale, void* w8, float* wscale, float* c, float* d, hipStream_t s) {
+    if (rows <= 0 || dim <= 0 || (dim & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold_ln_f8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, w, b, gamma, beta, rows, dim, scale,
+                       (uint8_t*)w8, wscale, c, d);
+    return hipGetLastError();
+}
+
 hipError_t launch_fold_ln(const float* w, const float* b, const float* gamma, const float* beta, int rows, int dim,
                           float scale, void* w16, float* c, float* d, int dtype, hipStream_t s) {
     if (rows <= 0 || dim <= 0) return hipErrorInvalidValue;

@@ -20,6 +20,8 @@ struct GemmArgs {
     const float* stats = nullptr;  // LNFOLD*: [M][2] (mean, rstd)
     void* out16 = nullptr;         // RESID_LN: 16-bit copy of the updated rows
     float* partials = nullptr;     // RESID_LN: [N/64][M][2]
+    const float* wscale = nullptr; // launch_gemm_fp8 with an LNFOLD* epilogue: the per-output-channel weight scales [N]
+                                   // (`aux` carries c_n there); every other fp8 epilogue passes them in `aux`
     // ping-pong forms 5 / 7 only: launch tiles [tile_begin, tile_begin + tile_count) of the n-fastest 256x256 tile order
     // (tile t = (t / tiles_n, t % tiles_n)); tile_count == 0 = all tiles.  Lets a caller split off the last, partly
     // filled round of tiles and overlap it with other work (vithip_api.hip, tail overlap).
@@ -80,6 +82,9 @@ hipError_t launch_rowstats_split(const float* x, int64_t rows, int dim, float ep
                                  hipStream_t stream);
 hipError_t launch_layernorm_split(const void* hi, const void* lo, int64_t rows, int dim, int64_t row_stride, const float* gamma,
                                   const float* beta, float eps, float* out32, int dtype, hipStream_t stream);
+// fp8 path: the folded weights as e4m3 rows + scales (wscale), c = wscale * sum of the decoded row, d as launch_fold_ln
+hipError_t launch_fold_ln_f8(const float* w, const float* b, const float* gamma, const float* beta, int rows, int dim,
+                             float scale, void* w8, float* wscale, float* c, float* d, hipStream_t stream);
 hipError_t launch_fold_ln(const float* w, const float* b, const float* gamma, const float* beta, int rows, int dim,
                           float scale, void* w16, float* c, float* d, int dtype, hipStream_t stream);
 // MLP mode: y = act(W x + b), W [n_out, n_in] fp32

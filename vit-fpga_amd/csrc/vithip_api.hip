@@ -263,7 +263,20 @@ int prepare_weights(vh_ctx* c) {
     hipStream_t s = c->stream;
     const float* P = c->params;
     HIPCHK(&c->err, launch_permute_patch(P + L.patch_w, D, f.channels, f.patch_size, c->wp16, c->dt16, s));
-    for (int l = 0; l < f.layers && c->fp8; ++l) {
+    for (int l = 0; l < f.layers && c->fp8 && c->ln_fold; ++l) {
+        // folded LayerNorm on e4m3 operands: W' = gamma o W through the row quantiser, its scales, c and d (launch_fold_ln_f8)
+        const LayerOff& o = L.layer[l];
+        float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
+        char* wq = (char*)c->wqkv16[l];
+        const size_t dd = (size_t)D * D;
+        HIPCHK(&c->err, launch_fold_ln_f8(P + o.qw, P + o.qb, P + o.ln1w, P + o.ln1b, D, D, kAttnQScale, wq, c->sqkv[l], cd, cd + 3 * D, s));
+        HIPCHK(&c->err, launch_fold_ln_f8(P + o.kw, P + o.kb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + dd, c->sqkv[l] + D, cd + D, cd + 4 * D, s));
+        HIPCHK(&c->err, launch_fold_ln_f8(P + o.vw, P + o.vb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + 2 * dd, c->sqkv[l] + 2 * D, cd + 2 * D, cd + 5 * D, s));
+        HIPCHK(&c->err, launch_quantize_rows(P + o.ow, D, D, 1.0f, c->wo16[l], c->so[l], s));
+        HIPCHK(&c->err, launch_fold_ln_f8(P + o.f1w, P + o.f1b, P + o.ln2w, P + o.ln2b, M, D, 1.0f, c->w1_16[l], c->s1[l], cd + 6 * D, cd + 6 * D + M, s));
+        HIPCHK(&c->err, launch_quantize_rows(P + o.f2w, D, M, 1.0f, c->w2_16[l], c->s2[l], s));
+    }
+    for (int l = 0; l < f.layers && c->fp8 && !c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
         // bias [bq/8 ; bk ; bv] from the 16-bit packer (its 16-bit matrix is overwritten right after), then
         // e4m3 rows + scales; the softmax scale 64^-1/2 * log2(e) (kAttnQScale) goes into the q rows' fp32 scales
@@ -368,12 +381,19 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         ev->push_back({stage, e});
         return VH_OK;
     };
+    // `wscale` (fp8 operands only): the weight matrix's per-output-channel scales
     auto gemm = [&](const void* a, const void* w, const float* bias, void* out, int64_t Mr, int N, int K, int epi,
-                    const float* aux, int aux_i) {
+                    const float* aux, int aux_i, const float* wscale = nullptr) {
         GemmArgs g{a, w, bias, out, Mr, N, K, epi, aux, aux_i, dt16, 0};
         g.stats = stats_p;         // read by LNFOLD*, ignored otherwise
-        g.out16 = epi == VH_EPI_RESID_SPLIT ? xlo16 : xn16;   // RESID_LN: the 16-bit copy; RESID_SPLIT: the lo plane
+        g.out16 = epi == VH_EPI_RESID_SPLIT ? xlo16 : xn16;   // RESID_LN: the 16-bit (fp8: e4m3) copy; RESID_SPLIT: the lo plane
         g.partials = partials_p;
+        if (wscale) {              // e4m3 operands (folded-LN layer loop of the fp8 path)
+            g.dtype = VH_DTYPE_FP8;
+            if (epi == VH_EPI_LNFOLD || epi == VH_EPI_LNFOLD_GELU) g.wscale = wscale;   // `aux` carries c_n there
+            else g.aux = wscale;
+            return launch_gemm_fp8(g, s);
+        }
         return launch_gemm(g, s);
     };
     // hip events around every launch of the stage selected by vh_set_stage_timing()
@@ -399,7 +419,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     if (c->ln_fold && nl > 0) {
         // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
         if (c->split) HIPCHK(&c->err, launch_rowstats_split(x, rows, D, f.ln_eps, xn16, xlo16, stats_p, dt16, s));
-        else HIPCHK(&c->err, launch_rowstats_cast(x, rows, D, f.ln_eps, xn16, stats_p, dt16, s));
+        else HIPCHK(&c->err, launch_rowstats_cast(x, rows, D, f.ln_eps, xn16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s));
         if ((rc = mark(ST_LNSTATS))) return rc;
     }
     for (int l = 0; l < nl && c->ln_fold; ++l) {
@@ -407,27 +427,29 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         const float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
         const int nblk = D / 64;
         if ((rc = tmark(ST_QKV))) return rc;
-        HIPCHK(&c->err, gemm(xn16, c->wqkv16[l], cd + 3 * D, qkv16, rows, 3 * D, D, VH_EPI_LNFOLD, cd, 0));
+        const float *sq = c->fp8 ? c->sqkv[l] : nullptr, *so = c->fp8 ? c->so[l] : nullptr;
+        const float *s1 = c->fp8 ? c->s1[l] : nullptr, *s2 = c->fp8 ? c->s2[l] : nullptr;
+        HIPCHK(&c->err, gemm(xn16, c->wqkv16[l], cd + 3 * D, qkv16, rows, 3 * D, D, VH_EPI_LNFOLD, cd, 0, sq));
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, dt16, c->tickets + img0, s));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, c->tickets + img0, s));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
         if (c->split) HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, xn16, rows, D, D, VH_EPI_RESID_SPLIT, nullptr, 0));
-        else HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows, D, D, VH_EPI_RESID_LN, nullptr, 0));
+        else HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows, D, D, VH_EPI_RESID_LN, nullptr, 0, so));
         if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
         HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows, D, f.ln_eps, stats_p, s));
         if ((rc = mark(ST_LNSTATS))) return rc;
         if ((rc = tmark(ST_FC1))) return rc;
-        HIPCHK(&c->err, gemm(xn16, c->w1_16[l], cd + 6 * D + M, h16, rows, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0));
+        HIPCHK(&c->err, gemm(xn16, c->w1_16[l], cd + 6 * D + M, h16, rows, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0, s1));
         if ((rc = tmark(ST_FC1))) return rc;
         if ((rc = mark(ST_FC1))) return rc;
         if ((rc = tmark(ST_FC2))) return rc;
         if (c->split) HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, xn16, rows, D, M, VH_EPI_RESID_SPLIT, nullptr, 0));
-        else HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, x, rows, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0));
+        else HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, x, rows, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0, s2));
         if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
         if (l + 1 < nl) {
@@ -745,10 +767,10 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     }
     c->fp8 = cfg->dtype == VH_DTYPE_FP8;
     c->dt16 = c->fp8 ? VH_DTYPE_BF16 : cfg->dtype;
-    if (c->fp8) c->ln_fold = false;
     {
+        // (fp8 operands: the fold runs on an e4m3 copy of the raw rows and keeps the fp32 residual -- no split planes)
         const char* e = getenv("VH_RESID_SPLIT");
-        c->split = c->ln_fold && !(e && e[0] == '0');
+        c->split = c->ln_fold && !c->fp8 && !(e && e[0] == '0');
     }
     const size_t o_cd = w16_bytes;
     w16_bytes += align_up((size_t)cfg->layers * (6 * D + 2 * M) * 4, 256);
