@@ -427,8 +427,11 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
     const int vx = ((vrow0 >> 1) & 1) << 6;           // same for rows +8, +16, +32*kt
     const int v0 = kv_bytes + vrow0 * 128 + (vcolb ^ vx);   // column block 1: ^ 64  (vcolb < 64)
 
+    // A workgroup walks HEADS (blockIdx, + grid, ...) and, inside a head, its query slabs back to back: the K/V image
+    // loaded for slab 0 serves every slab of the head (T = 577: two), and the ring is refilled with the next head's rows
+    // only during the head's LAST slab.  item = head * slabs + slab throughout.
     const int stride = (int)gridDim.x;
-    int item = blockIdx.x;
+    int item = blockIdx.x * slabs;
     const elem* cbase = kv_base(item);
     vec8 qf[4];
     if (wave < 4) {
@@ -451,7 +454,9 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
     const int tk_off = q_off + 4 * nw * 1024;              // the LDS word behind the Q staging
     unsigned int tkv = 0;                                  // ticket wave: the ticket in flight
     while (true) {
-        int next = item + stride;
+        const int slab_now = QS ? 0 : item - (item / slabs) * slabs;
+        const bool last_slab = QS || slab_now + 1 == slabs;
+        int next = QS ? item + stride : (last_slab ? (item / slabs + stride) * slabs : item + 1);
         if (QS && dyn && !first) {
             if (wave == nw - 1) {   // the ticket drawn at the top of the previous item (older than that item's 8 stores)
                 if (stored) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -461,7 +466,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
             }
         }
         const int b = QS ? (int)__umulhi((unsigned)item, heads_rcp) : (item / slabs) / heads;
-        const int slab = QS ? 0 : item - (item / slabs) * slabs;
+        const int slab = slab_now;
         const int h = (QS ? item : item / slabs) - b * heads;
         const int q0 = (slab * nw + wave) * 32;
 
@@ -484,6 +489,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
         if (QS && dyn && !first) { if (dbg_n_ < 3) dbg_[dbg_n_++] = (unsigned)next; next = item + stride; }
 #endif
         const bool has_next = (unsigned)next < (unsigned)nitems;
+        const bool refill = has_next && last_slab;            // the next item belongs to another head: stream its K/V in
         const elem* nbase = kv_base(has_next ? next : item);
         if (QS && dyn && has_next && wave == nw - 1 && lane == 0) {   // draw the ticket of the item after `next` (one lane)
             const unsigned int one = 1u, zero = 0u;
@@ -491,7 +497,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
             //  address half and the launch died with a memory aperture violation)
             asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(tkv) : "v"(zero), "v"(one), "s"(ticket) : "memory");
         }
-        if (!(VH_ATTN_ABL & 2) && !first && wave < 4) issue_tile(cbase, ntiles - 1);
+        if (!(VH_ATTN_ABL & 2) && !first && slab == 0 && wave < 4) issue_tile(cbase, ntiles - 1);   // (a later slab finds the whole image in place)
         if (QS) {   // this wave's Q fragments out of the staging area (free again after the barrier at the top of tile 1)
             const int qa = q_off + wave * 4096 + k0;
 #pragma unroll
@@ -632,7 +638,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
             if (!(VH_ATTN_ABL & 4)) ring_barrier();       // tile kt-1 is finished everywhere
             VH_ATT_T(3);   // middle tiles: barrier
             if (QS && kt == 1 && has_next && wave < 4) issue_q(nbase);
-            if (!(VH_ATTN_ABL & 2) && has_next && wave < 4) issue_tile(nbase, kt - 1);
+            if (!(VH_ATTN_ABL & 2) && refill && wave < 4) issue_tile(nbase, kt - 1);
             const VFrag vfr = load_v(kt);
             f32x16 sc = qk(kt, negm);
             softmax_pv(kt, sc, vfr, std::false_type{}, std::false_type{});
@@ -643,7 +649,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
         VH_ATT_T(5);   // last-tile wait
         if (!(VH_ATTN_ABL & 4)) ring_barrier();           // ... visible to every wave; tile nt-2 is finished everywhere
         VH_ATT_T(6);   // last-tile barrier
-        if (!(VH_ATTN_ABL & 2) && has_next && wave < 4) issue_tile(nbase, ntiles - 2);
+        if (!(VH_ATTN_ABL & 2) && refill && wave < 4) issue_tile(nbase, ntiles - 2);
         {
             const VFrag vfr = load_v(ntiles - 1);
             f32x16 sc = qk(ntiles - 1, negm);
@@ -727,7 +733,9 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     // staged-Q ring (counted waits): one slab of at least four waves whose trimmed images + staging fit twice in a CU
     const int G = (tokens + 7) / 8, G2 = (G + 1) & ~1;
     const size_t qs_lds = (size_t)(G + G2 + 4 * nw) * 1024 + 16;   // + the ticket word
-    if (std::is_same<T, TO>::value && want_ring >= 1 && want_ring != 2 && slabs == 1 && nw >= 4 && 2 * qs_lds <= 160 * 1024) {
+    // (16-bit output only: the e4m3-output instantiation of the staged form does not fit 128 VGPRs without spilling)
+    if constexpr (std::is_same<T, TO>::value)
+    if (want_ring >= 1 && want_ring != 2 && slabs == 1 && nw >= 4 && 2 * qs_lds <= 160 * 1024) {
         auto k = attention_ring_kernel<T, TO, true>;
         static int lds_done[kMaxDevices] = {0};
         if (hipError_t e = ensure_dynamic_lds((const void*)k, qs_lds, lds_done); e != hipSuccess) return e;
@@ -747,7 +755,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
         if (hipError_t e = ensure_dynamic_lds((const void*)k, one, lds_done); e != hipSuccess) return e;
         const int per_cu = (int)(160 * 1024 / one);       // co-resident workgroups per CU by LDS
         int grid = num_cu * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
-        if (grid > nitems) grid = nitems;
+        if (grid > batch * heads) grid = batch * heads;   // a workgroup walks heads; the slabs of a head share its K/V image
         hipLaunchKernelGGL(k, dim3(grid), dim3(nw * 64), one, s, (const typename T::elem*)qkv, (typename TO::elem*)out,
                            tokens, heads, slabs, ntiles, nitems, (unsigned int*)nullptr, 0u);
         return hipGetLastError();
