@@ -49,10 +49,10 @@ def test_tools_and_entry_points_compile():
     for rel in ("bench.py", "__graft_entry__.py", "tools/soak.py", "tools/parity_stats.py", "tools/pmc_summary.py",
                 "tools/gemm_bench.py", "tools/tiles_exp.py", "tools/fold_parity.py", "tests/golden/make_golden.py",
                 "tools/gemm_anatomy.py", "tools/torch_matmul_calib.py", "tools/parity_attribution.py", "tools/pmc_traffic.py",
-                "tests/cpu_leg.py"):
+                "tests/cpu_leg.py", "tools/attn_bench.py", "tools/attn_anatomy.py"):
         py_compile.compile(os.path.join(ROOT, rel), doraise=True)
     for rel in ("tools/power_probe.sh", "tools/ab_variant7.sh", "tools/ab_tail.sh", "tools/ab_supercol.sh", "tools/ab_attn.sh",
-                "tools/pmc_passes.sh"):
+                "tools/pmc_passes.sh", "tools/pmc_attn.sh", "tools/ab_attn_abl.sh", "tools/collect_round_evidence.sh"):
         subprocess.check_call(["bash", "-n", os.path.join(ROOT, rel)])
 
 
