@@ -270,6 +270,26 @@ def test_attention(dt, batch, tokens, heads):
     assert err <= ATT_TOL[dt], err
 
 
+@pytest.mark.parametrize("batch,tokens,heads,what", [
+    (92, 197, 12, "staged ring: 1104 items on 512 workgroups = two static items each, then 80 tickets from the work queue"),
+    (25, 577, 12, "plain ring: 300 heads x 2 slabs on 256 workgroups = K/V shared by the slabs, refilled for a second head")])
+def test_attention_persistent_workgroups_walk_several_items(batch, tokens, heads, what):
+    # the shapes of test_attention give every workgroup ONE item; these make the persistent loops, the ring refill across
+    # items, the slab sharing and the device work queue do real work (fp16: the tighter tolerance)
+    dt = vithip.DTYPE_FP16
+    D = heads * 64
+    qkv = rnd16((S.fill(batch * tokens * 3 * D, 12, 1, 0) * 1.5).reshape(batch * tokens, 3 * D), dt)
+    pre, qkv = prescale_q(qkv, D, dt)
+    ref = O.attention(qkv, batch, tokens, heads)
+    out = vithip.DeviceBuffer(batch * tokens * D * 2)
+    for _ in range(2):   # twice: the queue counter is re-armed by every launch
+        vithip.op_attention(dev(vithip.to16(pre, dt)).ptr, batch, tokens, heads, out.ptr, dt)
+        got = vithip.from16(out.to_numpy(np.uint16, (batch * tokens, D)), dt)
+        assert np.isfinite(got).all()
+        per_image = np.abs(got - ref).reshape(batch, -1).max(1) / np.abs(ref).max()
+        assert per_image.max() <= ATT_TOL[dt], (what, int(per_image.argmax()), float(per_image.max()))
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_attention_spiked_scores_force_rescale(dt):
     # one key row aligned with one query row far above the rest: the running max jumps in a late
