@@ -111,7 +111,33 @@ def make_blob(cfg, seed, ln_eps=1e-6):
     return blob
 
 
+# Results of the (deterministic) oracle forward, keyed by a hash of everything that goes in: the GPU suite asks for the
+# same reference again and again (one per operand type, LayerNorm path, fp8 reading ...) and the CPU forward is what
+# that suite spends its time on.  Test infrastructure only.
+_FWD_CACHE = {}
+
+
+def _fwd_key(cfg, blob, images, n_layers, ln_eps, fp8, want_hidden):
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    h.update(repr((sorted(cfg.items()), n_layers, float(ln_eps), str(fp8), bool(want_hidden), images.shape)).encode())
+    h.update(memoryview(np.ascontiguousarray(blob)).cast("B"))
+    h.update(memoryview(np.ascontiguousarray(images)).cast("B"))
+    return h.digest()
+
+
 def vit_forward(cfg, blob, images, n_layers=-1, threads=0, want_hidden=False, ln_eps=1e-6, fp8=False):
+    images = _f32(images)
+    key = _fwd_key(cfg, blob, images, n_layers, ln_eps, fp8, want_hidden)
+    hit = _FWD_CACHE.get(key)
+    if hit is None:
+        if len(_FWD_CACHE) >= 64:
+            _FWD_CACHE.clear()
+        hit = _FWD_CACHE[key] = _vit_forward_uncached(cfg, blob, images, n_layers, threads, want_hidden, ln_eps, fp8)
+    return (hit[0].copy(), hit[1].copy()) if want_hidden else hit.copy()
+
+
+def _vit_forward_uncached(cfg, blob, images, n_layers=-1, threads=0, want_hidden=False, ln_eps=1e-6, fp8=False):
     """fp8=True: the emulation of the device's VH_DTYPE_FP8 data flow (oracle.h, oracle_vit_forward_fp8);
     fp8="folded": the same with the LayerNorm folded into q|k|v and fc1 (oracle_vit_forward_fp8_folded)."""
     c = cfg_struct(cfg, ln_eps)

@@ -58,16 +58,17 @@ def test_logits_match_oracle(dt, name, batch):
 
 def test_vit_large_384_long_sequence_config():
     # BASELINE.json config 4 as a parity case: ViT-L/16 at 384x384 (T = 577 tokens, 24 layers, fp16).
-    # One image keeps the CPU oracle at ~0.4 TFLOP; exercises the 152 KiB LDS-resident K/V path.
+    # Two images keep the CPU oracle at ~0.8 TFLOP (the same two the full-size test of config 4 checks, so the oracle
+    # result is computed once per session); exercises the 152 KiB LDS-resident K/V path.
     cfg = S.CONFIGS["vit_large_384"]
     blob = S.make_blob(cfg, seed=0)
-    images = S.make_images(cfg, seed=1, batch=1)
+    images = S.make_images(cfg, seed=1, batch=2)
     ref = O.vit_forward(cfg, blob, images)
-    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=1)
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=2)
     ctx.load_weights(blob)
     got = ctx.forward(images)
     e = rel(got, ref)
-    print(f"\n[parity] vit_large_384 b1 fp16: logits {e:.3e}")
+    print(f"\n[parity] vit_large_384 b2 fp16: logits {e:.3e}")
     assert np.isfinite(got).all() and e <= NORTH_STAR, e
     ctx.close()
 
