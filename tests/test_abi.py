@@ -52,7 +52,7 @@ def test_tools_and_entry_points_compile():
                 "tests/cpu_leg.py", "tools/attn_bench.py", "tools/attn_anatomy.py"):
         py_compile.compile(os.path.join(ROOT, rel), doraise=True)
     for rel in ("tools/power_probe.sh", "tools/ab_variant7.sh", "tools/ab_tail.sh", "tools/ab_supercol.sh", "tools/ab_attn.sh",
-                "tools/pmc_passes.sh", "tools/pmc_attn.sh", "tools/ab_attn_abl.sh", "tools/collect_round_evidence.sh"):
+                "tools/pmc_passes.sh", "tools/pmc_attn.sh", "tools/ab_attn_abl.sh", "tools/collect_round_evidence.sh", "tools/ab_supercol_traffic.sh"):
         subprocess.check_call(["bash", "-n", os.path.join(ROOT, rel)])
 
 

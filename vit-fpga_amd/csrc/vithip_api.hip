@@ -294,6 +294,7 @@ int prepare_weights(vh_ctx* c) {
     // VH_FLAG_W8_E4M3: the six matrices of a layer pass through the e4m3 quantiser (one scale per output channel) and back
     // before the 16-bit preparation -- weight-only fp8 with dequantisation at load (SURVEY.md section 7 option (a))
     float* w8tmp = nullptr;
+    struct FreeOnExit { float*& p; ~FreeOnExit() { if (p) { hipFree(p); p = nullptr; } } } w8tmp_guard{w8tmp};   // every early return below frees the scratch
     const size_t dd1 = (size_t)D * D, md1 = (size_t)M * D;
     if (!c->fp8 && (f.flags & VH_FLAG_W8_E4M3)) { HIPCHK(&c->err, hipMalloc((void**)&w8tmp, (4 * dd1 + 2 * md1) * sizeof(float))); }
     for (int l = 0; l < f.layers && !c->fp8; ++l) {
@@ -304,10 +305,7 @@ int prepare_weights(vh_ctx* c) {
             const int rows[6] = {D, D, D, D, M, D}, cols[6] = {D, D, D, D, D, M};
             size_t at = 0;
             for (int i = 0; i < 6; ++i) {
-                if (hipError_t e = launch_fake_quant_rows(c->params + src[i], rows[i], cols[i], w8tmp + at, s); e != hipSuccess) {
-                    hipFree(w8tmp);
-                    return fail(&c->err, VH_ERR_HIP, "weight-only e4m3 quantiser: %s", hipGetErrorString(e));
-                }
+                HIPCHK(&c->err, launch_fake_quant_rows(c->params + src[i], rows[i], cols[i], w8tmp + at, s));
                 at += (size_t)rows[i] * cols[i];
             }
             // the matrix offsets now point into w8tmp (relative to P = w8tmp - 0): rebase through pointer arithmetic
@@ -334,7 +332,6 @@ int prepare_weights(vh_ctx* c) {
         if (w8tmp) { HIPCHK(&c->err, hipStreamSynchronize(s)); }   // the scratch is reused by the next layer
     }
     HIPCHK(&c->err, hipStreamSynchronize(s));
-    if (w8tmp) hipFree(w8tmp);
     c->weights_ready = true;
     return VH_OK;
 }
