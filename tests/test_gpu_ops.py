@@ -270,6 +270,26 @@ def test_attention(dt, batch, tokens, heads):
     assert err <= ATT_TOL[dt], err
 
 
+def test_attention_token_counts_around_every_kernel_boundary():
+    # one-shot form (T <= 96), staged ring (97..~208), plain ring (1 slab up to 384, 2 slabs beyond), LDS limit (640):
+    # token counts on both sides of each boundary and of the 32-key tile / 8-row group edges, several items per workgroup
+    # where that is cheap (fp16, the tighter tolerance)
+    dt = vithip.DTYPE_FP16
+    for tokens, batch, heads in ((33, 3, 2), (64, 2, 1), (65, 2, 2), (96, 5, 1), (97, 5, 1), (100, 700, 1), (128, 3, 2), (129, 2, 1),
+                                 (160, 2, 1), (161, 300, 2), (193, 2, 1), (200, 2, 3), (208, 2, 1), (209, 2, 1), (224, 300, 1),
+                                 (225, 2, 1), (256, 2, 2), (289, 1, 2), (384, 1, 2), (385, 1, 3), (512, 1, 1), (513, 2, 1),
+                                 (608, 1, 2), (609, 1, 1), (640, 1, 2)):
+        D = heads * 64
+        qkv = rnd16((S.fill(batch * tokens * 3 * D, 13, tokens, 0) * 1.5).reshape(batch * tokens, 3 * D), dt)
+        pre, qkv = prescale_q(qkv, D, dt)
+        ref = O.attention(qkv, batch, tokens, heads)
+        out = vithip.DeviceBuffer(batch * tokens * D * 2)
+        vithip.op_attention(dev(vithip.to16(pre, dt)).ptr, batch, tokens, heads, out.ptr, dt)
+        got = vithip.from16(out.to_numpy(np.uint16, (batch * tokens, D)), dt)
+        err = np.abs(got - ref).reshape(batch, -1).max(1) / np.abs(ref).max()
+        assert np.isfinite(got).all() and err.max() <= ATT_TOL[dt], (tokens, batch, heads, int(err.argmax()), float(err.max()))
+
+
 @pytest.mark.parametrize("batch,tokens,heads,what", [
     (92, 197, 12, "staged ring: 1104 items on 512 workgroups = two static items each, then 80 tickets from the work queue"),
     (25, 577, 12, "plain ring: 300 heads x 2 slabs on 256 workgroups = K/V shared by the slabs, refilled for a second head")])

@@ -361,8 +361,8 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
 
     // ---- DMA of one key tile (32 rows of K and of V = 8 pieces of 1 KiB): waves 0-3 move one K and one V piece each
     auto kv_base = [&](int item) {
-        if (QS) {   // one slab; b = item / heads by the host's reciprocal (exact for item * heads < 2^32)
-            const int b = (int)__umulhi((unsigned)item, heads_rcp), h = item - b * heads;
+        if (QS) {   // one slab; b = item / heads by the host's reciprocal ceil(2^32 / heads) (exact for item * heads < 2^32; heads == 1 has no 32-bit reciprocal)
+            const int b = (heads == 1 ? item : (int)__umulhi((unsigned)item, heads_rcp)), h = item - b * heads;
             return qkv + (int64_t)b * tokens * ld + h * 64;
         }
         const int bh = item / slabs;
@@ -465,7 +465,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
                 if (lane == 0) *(volatile unsigned int __attribute__((address_space(3)))*)(uintptr_t)(lds0 + tk_off) = 2u * (unsigned)stride + tkv;
             }
         }
-        const int b = QS ? (int)__umulhi((unsigned)item, heads_rcp) : (item / slabs) / heads;
+        const int b = QS ? (heads == 1 ? item : (int)__umulhi((unsigned)item, heads_rcp)) : (item / slabs) / heads;
         const int slab = slab_now;
         const int h = (QS ? item : item / slabs) - b * heads;
         const int q0 = (slab * nw + wave) * 32;
