@@ -271,6 +271,25 @@ def test_full_size_config_4_vit_large_384_fp16_batch_256_properties():
     ctx.close()
 
 
+@pytest.mark.parametrize("dtype_name", ["fp16", "bf16", "fp8"])
+def test_a_batch_that_is_no_multiple_of_256_rows_agrees_bitwise_with_its_sub_batches(dtype_name):
+    # 100 images = 19 700 token rows: enough tiles for the 256x256 ping-pong GEMM but a ragged last row of tiles, so the
+    # forward takes that kernel's one-tile-per-workgroup form (the persistent form serves row counts that are multiples of
+    # 256).  Images are independent: sub-batches from both ends and the middle, which run through the small-shape kernels,
+    # must reproduce their rows of the 100-image run bit for bit -- for every operand type.
+    dt = {"fp16": vithip.DTYPE_FP16, "bf16": vithip.DTYPE_BF16, "fp8": vithip.DTYPE_FP8}[dtype_name]
+    cfg = S.CONFIGS["vit_base"]
+    B = 100
+    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B)
+    ctx.init_weights_seeded(0)
+    images = S.make_images(cfg, 1, B)
+    full = ctx.forward(images)
+    assert np.isfinite(full).all()
+    for lo, hi in ((0, 3), (49, 52), (97, 100)):
+        assert np.array_equal(ctx.forward(images[lo:hi]), full[lo:hi]), (dtype_name, lo, hi)
+    ctx.close()
+
+
 def test_batch_4096_crosses_the_2_to_31_element_mark():
     # BASELINE config 3's global batch on ONE device: 806 912 token rows; the MLP hidden tensor has 2.48e9 elements,
     # so every row * width product in the kernels must be 64-bit.  Checked through batch independence: images from
