@@ -271,22 +271,27 @@ def test_full_size_config_4_vit_large_384_fp16_batch_256_properties():
     ctx.close()
 
 
+@pytest.mark.parametrize("B", [100, 300])
 @pytest.mark.parametrize("dtype_name", ["fp16", "bf16", "fp8"])
-def test_a_batch_that_is_no_multiple_of_256_rows_agrees_bitwise_with_its_sub_batches(dtype_name):
-    # 100 images = 19 700 token rows: enough tiles for the 256x256 ping-pong GEMM but a ragged last row of tiles, so the
-    # forward takes that kernel's one-tile-per-workgroup form (the persistent form serves row counts that are multiples of
-    # 256).  Images are independent: sub-batches from both ends and the middle, which run through the small-shape kernels,
-    # must reproduce their rows of the 100-image run bit for bit -- for every operand type.
+def test_a_batch_that_is_no_multiple_of_256_rows_agrees_bitwise_with_its_sub_batches(dtype_name, B):
+    # Token-row counts that are not multiples of the 256-row GEMM tile.  100 images (19 700 rows): few tiles, the forward
+    # takes the ping-pong GEMM's one-tile-per-workgroup form with a ragged last row of tiles.  300 images (59 100 rows):
+    # the folded layer loop runs its GEMMs on 59 136 rows -- whole tiles, the persistent form -- and the 36 padding rows
+    # hold whatever the arena holds; nothing of them may reach a logit.  Images are independent: sub-batches from both
+    # ends and the middle, which run through the small-shape kernels, must reproduce their rows of the big run bit for
+    # bit -- for every operand type, and again on a second run (the padding rows have changed by then).
     dt = {"fp16": vithip.DTYPE_FP16, "bf16": vithip.DTYPE_BF16, "fp8": vithip.DTYPE_FP8}[dtype_name]
     cfg = S.CONFIGS["vit_base"]
-    B = 100
     ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B)
     ctx.init_weights_seeded(0)
     images = S.make_images(cfg, 1, B)
     full = ctx.forward(images)
     assert np.isfinite(full).all()
-    for lo, hi in ((0, 3), (49, 52), (97, 100)):
+    for lo, hi in ((0, 3), (B // 2, B // 2 + 3), (B - 3, B)):
         assert np.array_equal(ctx.forward(images[lo:hi]), full[lo:hi]), (dtype_name, lo, hi)
+    assert np.array_equal(ctx.forward(images), full)
+    ctx.set_streams(3)     # three concurrent parts: only the last one may pad (the others have a neighbour behind their rows)
+    assert np.array_equal(ctx.forward(images), full)
     ctx.close()
 
 
