@@ -20,6 +20,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement): whole-job image
   fp16         — the same measurement (value, roofline, parity) with fp16 MFMA operands, the operand
                  type that is inside the north star's tolerance (bf16, the dtype the headline config
                  names, is not and cannot be: DESIGN.md "Numerics");
+  vit_large_384_fp16_b256 / fp8_b512 — short measurements (value, roofline, parity) of BASELINE configs 4 and 5, so
+                 that the driver's record covers them too (default run only; `--no-extra-configs` skips them);
   cpu_baseline — the CPU oracle behind net::net_abstract (tests/cpp/net_cpu, a port: the reference has
                  no CPU path) timed through launch_forward on the host cores (N=1 only).
 """
@@ -66,6 +68,20 @@ def measured_traffic(config, batch, dtype, streams):
     return None, None
 
 
+def measured_clock(config, batch, dtype):
+    """In-kernel shader clock (GHz) of the fc1 GEMM's main loop from the diagnostic build's s_memtime / s_memrealtime
+    stamps (tools/gemm_anatomy.py --json), taken once per state of the kernel sources like the traffic file; or None."""
+    sha = source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_fc1_clock.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("source_sha") == sha and d.get("config") == config and d.get("batch") == batch and d.get("dtype") == dtype:
+            return d["clock_ghz"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +98,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed batch's first images")
     ap.add_argument("--parity-images", type=int, default=16)
     ap.add_argument("--no-fp16-line", action="store_true", help="skip the extra fp16 measurement of the default run")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short ViT-L/16-384 fp16 b256 and ViT-B/16 fp8 b512 measurements of the default run")
     ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even with one rank")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time table to stderr")
     ap.add_argument("--host-path", action="store_true",
@@ -118,18 +136,21 @@ def main():
     import vh_synth as S
     import vithip
 
-    cfg = S.CONFIGS[args.config]
-    B = args.batch
-    T = S.tokens(cfg)
-    flops_img = S.flops_per_image(cfg)
-
     def barrier():
         if use_dist:
             dist.barrier()
 
-    def measure(dtype_name, extras):
+    def measure(dtype_name, extras, config=None, B=None, steps=None, warmup=None, parity_images=None):
         """One complete measurement with `dtype_name` operands: context, weights (broadcast when distributed), warm-up,
         K timed steps, roofline of the fc1 kernel, parity of the timed batch's first images."""
+        config = config or args.config
+        cfg = S.CONFIGS[config]
+        B = B or args.batch
+        steps = steps or args.steps
+        warmup = args.warmup if warmup is None else warmup
+        parity_images = parity_images or args.parity_images
+        T = S.tokens(cfg)
+        flops_img = S.flops_per_image(cfg)
         dt = {"bf16": vithip.DTYPE_BF16, "fp16": vithip.DTYPE_FP16, "fp8": vithip.DTYPE_FP8}[dtype_name]
         ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B, device=local_rank,
                                 flags=vithip.FLAG_W8_E4M3 if args.weights == "e4m3" else 0)
@@ -166,52 +187,93 @@ def main():
             if use_dist:
                 torch.cuda.synchronize()
 
-        if args.warmup > 0:
-            ctx.forward_device_async(din.ptr, B, dout.ptr, steps=args.warmup)
+        if warmup > 0:
+            ctx.forward_device_async(din.ptr, B, dout.ptr, steps=warmup)
         sync()
 
         # ---- timed region: exactly K steps ----------------------------------------------------------------
+        # hip events on the context's stream inside it: around every fc1 launch (the roofline kernel) and at every step
+        # boundary (median / min step).  Their cost is in `value`; `events_cost` below measures it.
         if not args.graph:
             ctx.set_stage_timing("fc1_gemm")   # per-launch events would bypass the graph
+            ctx.set_step_timing(True)
         barrier(); sync()
         t0 = time.perf_counter()
-        ctx.forward_device_async(din.ptr, B, dout.ptr, steps=args.steps)
+        ctx.forward_device_async(din.ptr, B, dout.ptr, steps=steps)
         sync(); barrier()
         elapsed = time.perf_counter() - t0
         fc1_avg_ms, fc1_min_ms, fc1_n = ctx.get_stage_timing()
+        step_ms = sorted(ctx.get_step_timing()) if not args.graph else []
         ctx.set_stage_timing(None)
+        ctx.set_step_timing(False)
         if use_dist:
             elapsed = vh_dist.max_over_ranks(torch, dist, elapsed, f"cuda:{local_rank}")
+        # the same K steps once more WITHOUT any event in the stream (not the reported value: the measure of what the
+        # events inside the timed region cost)
+        elapsed_plain = None
+        if extras and not args.graph and not use_dist:
+            sync()
+            t1 = time.perf_counter()
+            ctx.forward_device_async(din.ptr, B, dout.ptr, steps=steps)
+            sync()
+            elapsed_plain = time.perf_counter() - t1
 
         logits = dout.to_numpy(np.float32, (B, cfg["classes"]))
         if not np.isfinite(logits).all():
             raise SystemExit("non-finite logits")
 
-        res = {"elapsed": elapsed, "streams": streams}
+        res = {"elapsed": elapsed, "streams": streams, "cfg": cfg, "B": B, "steps": steps, "flops_img": flops_img}
         if rank == 0:
-            ips = B * world * args.steps / elapsed
+            ips = B * world * steps / elapsed
             peak = PEAK_TFLOPS[dtype_name]
-            fc1_flops = 2.0 * (B / streams) * T * cfg["mlp_dim"] * cfg["dim"]  # every launch handles one part of the batch
+            rows = (B // streams) * T
+            fc1_flops = 2.0 * rows * cfg["mlp_dim"] * cfg["dim"]  # every launch handles one part of the batch
             achieved = fc1_flops / (fc1_avg_ms * 1e-3) / 1e12 if fc1_avg_ms > 0 else 0.0
             fold = ctx.ln_fold()
-            persistent = os.environ.get("VH_GEMM_PP") in (None, "", "0", "6")
+            # the form the launcher really picks for this row count (vithip_api.hip enqueue_forward + kernels_gemm5.hip
+            # launch_pp): persistent when the rows fill whole 256-row tiles, or when the folded layer loop pads them
+            # (at least two rounds of tiles); the one-tile-per-workgroup form otherwise, or when VH_GEMM_PP forces it
+            row_tiles = (rows + 255) // 256
+            padded = fold and row_tiles * ((cfg["dim"] + 255) // 256) >= 2 * 256
+            persistent = os.environ.get("VH_GEMM_PP") in (None, "", "0", "6") and (rows % 256 == 0 or padded) \
+                and cfg["mlp_dim"] % 256 == 0 and row_tiles * (cfg["mlp_dim"] // 256) >= 128
             kname = ("gemm_nt_pp_kernel<%s%s> 256x256x%d %sping-pong (fc1)" %
                      ("LN-fold+bias+GELU" if fold else "bias+GELU", ", e4m3" if dtype_name == "fp8" else "",
                       128 if dtype_name == "fp8" else 64, "persistent " if persistent else ""))
-            traffic, tsrc = measured_traffic(args.config, B, dtype_name, streams)
+            traffic, tsrc = measured_traffic(config, B, dtype_name, streams)
+            clk, csrc = measured_clock(config, B, dtype_name)
+            roof = None
+            if not args.graph:
+                roof = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "concurrent_parts": streams, "flop_per_launch": fc1_flops, "avg_launch_ms": round(fc1_avg_ms, 5),
+                        "min_launch_ms": round(fc1_min_ms, 5), "launches_timed": fc1_n}
+                # what the chip can deliver at the clock it HOLDS inside this kernel (DVFS): in-kernel clock x 4096 FLOP
+                # per clock and CU (16-bit; 8192 for e4m3 operands) x 256 CUs.  `frac` (against the nominal 2.4 GHz peak)
+                # stays the graded figure; frac_of_attainable separates clock loss from schedule loss.
+                if clk:
+                    att = clk * 1e9 * (8192 if dtype_name == "fp8" else 4096) * 256 / 1e12
+                    roof.update({"attainable": round(att, 1), "frac_of_attainable": round(achieved / att, 4),
+                                 "clock_ghz_in_kernel": clk, "clock_source": csrc})
+                else:
+                    roof.update({"attainable": None, "frac_of_attainable": None})
             res.update({
-                "value": round(ips, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "value": round(ips, 2), "ms_per_step": round(elapsed / steps * 1e3, 4),
                 "forward_mfma_frac": round(ips / world * flops_img / (peak * 1e12), 4),
-                "roofline": None if args.graph else {
-                    "bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc,
-                    "concurrent_parts": streams, "flop_per_launch": fc1_flops, "avg_launch_ms": round(fc1_avg_ms, 5),
-                    "min_launch_ms": round(fc1_min_ms, 5), "launches_timed": fc1_n},
+                "roofline": roof,
             })
+            if step_ms:
+                res["step_ms"] = {"median": round(step_ms[len(step_ms) // 2], 4), "min": round(step_ms[0], 4),
+                                  "max": round(step_ms[-1], 4), "steps": len(step_ms),
+                                  "note": "device time between the hip events at the step boundaries (rank 0)"}
+            if elapsed_plain:
+                res["events_cost"] = {"value_without_events": round(B * steps / elapsed_plain, 2),
+                                      "note": "the same K steps run again with no hip event in the stream; `value` is the run WITH "
+                                              "the roofline / step events, as the timed region is defined"}
             if not args.no_parity:
-                res["parity"] = parity_of(cfg, logits, min(args.parity_images, B), dtype_name, 1 + rank, np, S)
+                res["parity"] = parity_of(cfg, logits, min(parity_images, B), dtype_name, 1 + rank, np, S)
             if extras and args.host_path:
-                res["host_path"] = host_path_rate(ctx, cfg, B, args.steps, np, S)
+                res["host_path"] = host_path_rate(ctx, cfg, B, steps, np, S)
             if extras and args.stages:
                 res["stages"] = ctx.profile_forward(din.ptr, B, dout.ptr)
         din.free(); dout.free()
@@ -219,10 +281,16 @@ def main():
         return res
 
     main_res = measure(args.dtype, True)
+    cfg, B, flops_img = main_res["cfg"], main_res["B"], main_res["flops_img"]
     fp16_res = None
+    extra_res = {}
     default_run = args.config == "vit_base" and B == 512 and args.dtype == "bf16"
     if default_run and not args.no_fp16_line and not args.graph:
         fp16_res = measure("fp16", False)
+    if default_run and not args.no_extra_configs and not args.graph and world == 1:
+        # BASELINE configs 4 and 5, short: about a second of GPU time each
+        extra_res["vit_large_384_fp16_b256"] = measure("fp16", False, config="vit_large_384", B=256, steps=5, warmup=1, parity_images=2)
+        extra_res["fp8_b512"] = measure("fp8", False, config="vit_base", B=512, steps=10, warmup=2, parity_images=8)
 
     if rank == 0:
         streams = main_res["streams"]
@@ -231,7 +299,7 @@ def main():
         out = {
             "metric": "images/sec ViT-B/16 224x224, batch 512 per GPU" if default_run
                       else f"images/sec {args.config} {args.dtype} batch {B} per GPU",
-            "value": main_res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": main_res["value"], "unit": "images/s", "n_gpus": world, "steps": main_res["steps"], "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config} {cfg['image_size']}x{cfg['image_size']}x{cfg['channels']} inference, "
@@ -241,12 +309,19 @@ def main():
             "forward_mfma_frac": main_res["forward_mfma_frac"],
             "roofline": main_res["roofline"],
         }
-        if "parity" in main_res:
-            out["parity"] = main_res["parity"]
+        for k in ("step_ms", "events_cost", "parity"):
+            if k in main_res:
+                out[k] = main_res[k]
         if args.graph:
             out["graph"] = True
+        for name, r in extra_res.items():
+            out[name] = {k: r[k] for k in ("value", "ms_per_step", "forward_mfma_frac", "roofline", "step_ms", "parity") if k in r}
+            out[name]["steps"] = r["steps"]
+            out[name]["note"] = ("BASELINE config 4: ViT-L/16 384x384 fp16, 256 images, 1 GPU (short run)" if name.startswith("vit_large")
+                                 else "BASELINE config 5: ViT-B/16, e4m3 operands in the four per-layer GEMMs (VH_DTYPE_FP8), 512 images, "
+                                      "1 GPU (short run; fraction of the 5 PF dense fp8 peak)")
         if fp16_res:
-            out["fp16"] = {k: fp16_res[k] for k in ("value", "ms_per_step", "forward_mfma_frac", "roofline", "parity") if k in fp16_res}
+            out["fp16"] = {k: fp16_res[k] for k in ("value", "ms_per_step", "forward_mfma_frac", "roofline", "step_ms", "parity") if k in fp16_res}
             out["fp16"]["note"] = ("same workload, same run, fp16 MFMA operands: the operand type inside the north star's 1e-3 "
                                    "(extra object; `value` above is the bf16 configuration BASELINE.json names)")
         if not args.no_cpu_baseline and world == 1:

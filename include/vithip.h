@@ -75,13 +75,24 @@ typedef struct vh_config {
     int32_t flags;      /* VH_FLAG_* (0 = library defaults); unknown bits are rejected */
 } vh_config;
 
-/* vh_config.flags.  LayerNorm folding: with dim and mlp_dim multiples of 256 the two LayerNorms of a layer are folded
- * into the neighbouring GEMMs by default (DESIGN.md "LayerNorm folded into the GEMMs"): the GEMM then multiplies the
- * RAW 16-bit-rounded residual rows.  The choice depends on the model shape and these flags ONLY (never on max_batch),
- * so a given image gives the same logit bits from every context of one configuration.  The folded operand's rounding
- * error grows with |row mean| / row sigma; for activations with a large common-mode offset choose VH_FLAG_LN_FOLD_OFF. */
+/* vh_config.flags.  LayerNorm folding: with dim and mlp_dim multiples of 256 the two LayerNorms of a layer can be folded
+ * into the neighbouring GEMMs (DESIGN.md "LayerNorm folded into the GEMMs"): the GEMM then multiplies the RAW
+ * 16-bit-rounded residual rows, whose rounding error relative to the centred signal grows with
+ * sqrt(1 + (row mean / row sigma)^2).  Three settings:
+ *   flags == 0 (default)   the GUARDED fold: folded, and every forward measures max |mean| / sigma over its rows
+ *                          (vh_get_ln_guard).  Once a completed forward has exceeded the threshold (0.5; environment
+ *                          VH_LN_GUARD) the context switches to the stand-alone LayerNorm for good (the weights are
+ *                          prepared again from the resident blob), and the synchronous vh_forward repeats the very
+ *                          forward that tripped it, so what it returns is always inside the fold's error budget.
+ *   VH_FLAG_LN_FOLD_ON     always folded: the explicit throughput choice.  The guard still measures, never switches.
+ *   VH_FLAG_LN_FOLD_OFF    always the stand-alone LayerNorm kernel.
+ * With ON or OFF the path depends on the model shape and the flags ONLY (never on max_batch or on the data), so a given
+ * image gives the same logit bits from every context of one configuration; with the default it depends, in addition, on
+ * whether the guard has tripped (vh_get_ln_fold tells).  Environment overrides, honoured only when flags == 0 and meant
+ * for A/B tools: VH_LN_FOLD=0|1 (forces the path and disables the switch), VH_RESID_SPLIT=0 (fp32 residual stream instead
+ * of the two 16-bit planes). */
 #define VH_FLAG_LN_FOLD_OFF 1 /* always run the stand-alone LayerNorm kernel                */
-#define VH_FLAG_LN_FOLD_ON 2  /* fold where the shapes allow it (the default, stated explicitly) */
+#define VH_FLAG_LN_FOLD_ON 2  /* always fold where the shapes allow it (no run-time switch)  */
 /* Weight-only e4m3 (16-bit dtypes only): the q, k, v, out-projection, fc1 and fc2 matrices are quantised to OCP e4m3
  * with one fp32 scale per output channel when the weights are loaded and dequantised again before the 16-bit
  * preparation, so the GEMMs multiply 16-bit activations with e4m3-valued weights (SURVEY.md section 7 option (a); the
@@ -116,6 +127,10 @@ int vh_destroy(vh_ctx* ctx);
 int vh_get_config(const vh_ctx* ctx, vh_config* out);
 /* *on = 1 when this context folds its LayerNorms into the GEMMs (vh_config.flags, model shape, dtype) */
 int vh_get_ln_fold(const vh_ctx* ctx, int* on);
+/* the fold's run-time guard (see VH_FLAG_LN_FOLD_*): *max_ratio = the largest |row mean| / row sigma any LayerNorm input
+ * row has shown since the weights were loaded (0 when the context never folded), *threshold = the switch point,
+ * *tripped = 1 once it was exceeded.  Synchronises the context's stream.  Any pointer may be NULL. */
+int vh_get_ln_guard(vh_ctx* ctx, float* max_ratio, float* threshold, int* tripped);
 
 /* Weight blob = fp32 tensors in canonical order (DESIGN.md "weight blob") preceded by a
  * 64-byte header.  Replaces _load_params (netFPGA.cpp:484-515): uploads, converts to the
@@ -209,10 +224,16 @@ const char* vh_stage_name(int stage_index);
  * minimum launch duration and the number of launches measured. */
 int vh_set_stage_timing(vh_ctx* ctx, int stage_index);
 int vh_get_stage_timing(vh_ctx* ctx, double* avg_ms, double* min_ms, int* launches);
+/* Per-STEP device times of the last vh_forward_device_async call: with step timing enabled the call records one hip
+ * event at every step boundary (K + 1 for K steps, on the context's stream); vh_get_step_timing synchronises and writes
+ * the first min(*steps, max_steps) step durations in ms (bench.py: median and min beside the mean). */
+int vh_set_step_timing(vh_ctx* ctx, int enable);
+int vh_get_step_timing(vh_ctx* ctx, double* step_ms, int max_steps, int* steps);
 
 /* debug taps: copy an internal activation of the LAST forward to the host as fp32.
  * what: 0 = residual stream x [batch*T, D] after the last layer run,
- *       1 = final-LN'd CLS rows [batch, D]. */
+ *       1 = final-LN'd CLS rows [batch, D],
+ *       2 = one float: how many residual GEMMs of the last forward ran as a split launch (VH_TAIL_OVERLAP=1). */
 int vh_debug_read(vh_ctx* ctx, int what, float* host_out, size_t n_floats);
 /* run only the first `n_layers` encoder layers on the next forwards (-1 = all) */
 int vh_debug_set_layers(vh_ctx* ctx, int n_layers);

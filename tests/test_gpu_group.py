@@ -64,6 +64,21 @@ def test_group_of_one_through_rccl(monkeypatch):
     assert np.array_equal(got, plain(cfg, blob, images, vithip.DTYPE_BF16))
 
 
+def test_group_of_two_distinct_devices_through_rccl():
+    """The real N > 1 path: two DISTINCT devices, ncclCommInitAll + grouped ncclBroadcast over xGMI, one host thread per
+    device.  Skips -- explicitly, it does not pass as a rehearsal -- on a box with fewer than two GPUs; until a multi-GPU
+    run exists the RCCL broadcast between distinct devices is unverified on hardware."""
+    if vithip.device_count() < 2:
+        pytest.skip("needs 2 GPUs: the RCCL broadcast between distinct devices has never run on hardware (one-GPU boxes)")
+    cfg = S.CONFIGS["vit_mini"]
+    blob, images = S.make_blob(cfg, 3), S.make_images(cfg, 4, 7)
+    want = plain(cfg, blob, images, vithip.DTYPE_BF16)
+    g = vithip.VitGroup(cfg, [0, 1], dtype=vithip.DTYPE_BF16, max_batch_per_device=7)
+    g.load_weights(blob)
+    assert np.array_equal(g.forward(images), want)
+    g.close()
+
+
 def test_non_zero_rank_weight_hand_over_then_shard_forward():
     """What rank r > 0 of the one-process-per-GPU form does (bench.py, vh_dist): rank 0 exports the canonical blob into a
     device buffer, the buffer is broadcast (here: used as is), the other rank calls vh_load_weights_device on it and runs

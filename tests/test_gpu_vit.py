@@ -74,11 +74,11 @@ def test_vit_large_384_long_sequence_config():
 
 
 @pytest.mark.parametrize("flags,label", [(vithip.FLAG_LN_FOLD_ON, "folded"), (vithip.FLAG_LN_FOLD_OFF, "stand-alone")])
-def test_fp16_is_inside_the_north_star_tolerance_on_32_vit_b_images(flags, label):
-    """The configuration that carries the parity claim: ViT-B/16, fp16 operands, 32 images, BOTH LayerNorm paths; the worst
-    image must be inside 1e-3 (not the mean, not a sample of two)."""
+def test_fp16_is_inside_the_north_star_tolerance_on_64_vit_b_images(flags, label):
+    """The configuration that carries the parity claim: ViT-B/16, fp16 operands, 64 images, BOTH LayerNorm paths; the worst
+    image must be inside 1e-3 (not the mean, not a sample of two).  (Round 2 asserted 32 here and kept 64 in a tool.)"""
     cfg = S.CONFIGS["vit_base"]
-    n = 32
+    n = 64
     blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, n)
     ref = O.vit_forward(cfg, blob, images)
     ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=n, flags=flags)
@@ -131,6 +131,61 @@ def test_folded_layernorm_with_a_large_common_mode_row_mean():
     assert ratio > 3.0
     assert err[vithip.FLAG_LN_FOLD_OFF] <= NORTH_STAR
     assert err[vithip.FLAG_LN_FOLD_ON] <= 1.5 * NORTH_STAR * np.sqrt(1.0 + ratio * ratio)
+    # DEFAULT flags = the guarded fold: the forward measures max |mean| / sigma over its rows, finds it beyond the
+    # threshold, switches the context to the stand-alone LayerNorm and (synchronous entry point) repeats the forward --
+    # what the caller gets is inside the tolerance, and the context stays on the safe path afterwards.
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=4)
+    ctx.load_weights(blob)
+    assert ctx.ln_fold()
+    got = ctx.forward(images)
+    seen, thresh, tripped = ctx.ln_guard()
+    print(f"[fold] default flags: guard saw {seen:.2f} (threshold {thresh:.2f}), tripped {tripped}, folded now {ctx.ln_fold()}, "
+          f"error {rel(got, ref):.3e}")
+    assert tripped and seen > 3.0 and not ctx.ln_fold()
+    assert rel(got, ref) <= NORTH_STAR
+    # the asynchronous device-pointer path switches at the NEXT call (no synchronisation inside): its second forward is safe
+    d_in, d_out = vithip.DeviceBuffer.from_numpy(images), vithip.DeviceBuffer(4 * cfg["classes"] * 4)
+    ctx2 = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=4)
+    ctx2.load_weights(blob)
+    ctx2.forward_device_async(d_in.ptr, 4, d_out.ptr, steps=1)
+    ctx2.synchronize()
+    assert ctx2.ln_fold()                      # nothing has looked at the guard word yet
+    ctx2.forward_device_async(d_in.ptr, 4, d_out.ptr, steps=1)
+    ctx2.synchronize()
+    assert not ctx2.ln_fold()
+    got2 = d_out.to_numpy(np.float32, (4, cfg["classes"]))
+    assert np.array_equal(got2, got)           # the stand-alone path, same bits as the repeated synchronous forward
+    # new weights re-arm the guard and restore the configured path
+    ctx2.load_weights(S.make_blob(cfg, 0))
+    assert ctx2.ln_fold() and ctx2.ln_guard() == (0.0, thresh, False)
+    ctx2.close()
+    ctx.close()
+
+
+def test_default_guarded_fold_stays_folded_on_the_synthetic_nets_and_on_outlier_channels():
+    """What trained ViTs show is not a common-mode offset but a few OUTLIER CHANNELS: 6 channels of the position embedding,
+    the class token and the patch bias scaled by 50.  That leaves |row mean| / sigma small (the guard must not trip) and
+    costs the folded operand nothing -- 16-bit rounding is relative per element -- so both LayerNorm paths stay inside the
+    north star's 1e-3 (fp16)."""
+    cfg = S.CONFIGS["vit_base"]
+    t = S.make_tensors(cfg, 0)
+    ch = np.array([5, 77, 190, 333, 501, 700])
+    for name in ("pos", "cls", "patch.bias"):
+        t[name] = t[name].copy()
+        t[name][..., ch] *= np.float32(50.0)
+    blob = S.pack_blob(cfg, t)
+    images = S.make_images(cfg, 1, 4)
+    ref = O.vit_forward(cfg, blob, images)
+    for flags, name in ((0, "guarded fold (default)"), (vithip.FLAG_LN_FOLD_OFF, "stand-alone")):
+        ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=4, flags=flags)
+        ctx.load_weights(blob)
+        e = rel(ctx.forward(images), ref)
+        seen, thresh, tripped = ctx.ln_guard()
+        print(f"\n[outliers] {name}: {e:.3e}; guard saw {seen:.3f} of {thresh:.2f}")
+        assert e <= NORTH_STAR, (name, e)
+        if flags == 0:
+            assert ctx.ln_fold() and not tripped and 0.0 < seen < thresh
+        ctx.close()
 
 
 @pytest.mark.parametrize("dt", DT_PARAMS)
@@ -398,6 +453,9 @@ def test_tail_overlap_split_launch_is_bit_identical(monkeypatch):
         ctx.fill_input_seeded(5, B, din.ptr)
         ctx.forward_device(din.ptr, B, dout.ptr)
         outs[flag] = dout.to_numpy(np.float32, (B, cfg["classes"]))
+        # the option must really split: 2 residual GEMMs per layer, the last fc2 has no LayerNorm behind it
+        splits = int(ctx.debug_read(2, 1)[0])
+        assert splits == (2 * cfg["layers"] - 1 if flag == "1" else 0), (flag, splits)
         ctx.close()
     assert np.isfinite(outs["0"]).all() and np.array_equal(outs["0"], outs["1"])
 

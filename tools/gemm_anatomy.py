@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--launches", type=int, default=64, help="most recent ping-pong launches to analyse")
+    ap.add_argument("--clock-json", default=None,
+                    help="write the in-kernel clock of the fc1 GEMM's main loop (with the hash of the kernel sources) to this "
+                         "file: bench.py's roofline.attainable reads profiles/*_fc1_clock.json")
     args = ap.parse_args()
 
     L = vithip.lib()
@@ -121,6 +124,14 @@ def main():
         mfma_cycles = nk * 2048.0          # per SIMD per tile: 2 waves x 64 MFMAs x 16 cycles per K-tile (fp8: 32 x 32)
         c = float(np.mean(clk))
         m_us = float(np.mean(mainl))
+        if args.clock_json and N == cfg["mlp_dim"] and K == cfg["dim"] and not f8 == (args.dtype != "fp8"):
+            import json
+            sys.path.insert(0, ROOT)
+            import bench
+            json.dump({"source_sha": bench.source_sha(), "config": args.config, "batch": B, "dtype": args.dtype,
+                       "clock_ghz": round(c, 4), "kernel": "fc1 GEMM main loop (d s_memtime / d s_memrealtime x 100 MHz, median over "
+                       "workgroups, diagnostic build, after >= 2 s of back-to-back forwards)", "launches": len(launches)},
+                      open(args.clock_json, "w"), indent=1)
         busy = 100.0 * mfma_cycles / (m_us * c * 1e3) if m_us > 0 else 0.0
         tile_us = np.mean(pro) + m_us + np.mean(epi_t) + np.mean(drain) + (np.mean(gaps) if gaps else 0.0)
         tiles = ((M + 255) // 256) * ((N + 255) // 256)
@@ -128,6 +139,18 @@ def main():
         print(f"{M:7d} {N:5d} {K:5d} {EPI.get(epi, str(epi)):>16s}{' e4m3' if f8 else '':5s} v{variant} {len(launches):8d} {tiles:6d} {np.mean(span):8.1f} | "
               f"{'':13s} {np.mean(pro):8.2f} {m_us:7.2f} {np.mean(epi_t):9.2f} {np.mean(drain):6.2f} {np.mean(gaps) if gaps else float('nan'):6.2f} | "
               f"{c:7.3f} {busy:18.1f} {100.0 * m_us / tile_us:11.1f} {pf:6.3f}")
+        # are the workgroups of a launch in step?  spread over the workgroups of the absolute time (chip-wide 100 MHz
+        # counter) at which each one finished the stamped tile's main loop, i.e. started its epilogue
+        sp = []
+        for st8 in launches:
+            s0 = st8[:, 0, :].astype(np.int64)
+            s0 = s0[s0[:, 4] > 0]
+            if len(s0) > 8:
+                t = s0[:, 2] / 100.0
+                sp.append([np.percentile(t, q) - np.median(t) for q in (5, 25, 75, 95)] + [t.std()])
+        if sp:
+            a = np.mean(np.array(sp), axis=0)
+            print(f"      epilogue start across the workgroups of a launch, us around the median: p5 {a[0]:+.2f}  p25 {a[1]:+.2f}  p75 {a[2]:+.2f}  p95 {a[3]:+.2f}  (sigma {a[4]:.2f})")
         if nwv:
             wv /= nwv
             print("      per wave (us after wave 0's top-of-tile stamp): loop entered | main loop done | epilogue issued | iteration end")

@@ -16,12 +16,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--no-torch", action="store_true", help="skip the torch.matmul column (A/B runs of two library builds)")
     args = ap.parse_args()
-    import torch
     import vithip
+    if args.no_torch:
+        M = 100864
+        print(f"# {os.environ.get('VITHIP_LIB', 'libvithip.so')}")
+        for name, N, K, epi in [("qkv", 2304, 768, vithip.EPI_LNFOLD), ("proj", 768, 768, vithip.EPI_RESID_SPLIT),
+                                ("fc1", 3072, 768, vithip.EPI_LNFOLD_GELU), ("fc2", 768, 3072, vithip.EPI_RESID_SPLIT)]:
+            v = min(vithip.bench_gemm(M, N, K, vithip.EPI_BIAS, vithip.DTYPE_BF16, 0, args.iters) for _ in range(args.rounds)) * 1e3
+            e = min(vithip.bench_gemm(M, N, K, epi, vithip.DTYPE_BF16, 0, args.iters) for _ in range(args.rounds)) * 1e3
+            fl = 2.0 * M * N * K
+            print(f"{name:6s} {N:5d} {K:5d} | plain bias: {v:8.1f} us {fl / v / 1e6:7.1f} TF | layer epilogue: {e:8.1f} us {fl / e / 1e6:7.1f} TF | +{100 * (e / v - 1):5.1f} %", flush=True)
+        return
+    import torch
     M = 100864
-    shapes = [("qkv", 2304, 768, vithip.EPI_BIAS), ("proj", 768, 768, vithip.EPI_BIAS_RESID),
-              ("fc1", 3072, 768, vithip.EPI_BIAS_GELU), ("fc2", 768, 3072, vithip.EPI_BIAS_RESID)]
+    # the epilogues the folded layer loop really launches (vh_bench_gemm allocates their statistics / second plane)
+    shapes = [("qkv", 2304, 768, vithip.EPI_LNFOLD), ("proj", 768, 768, vithip.EPI_RESID_SPLIT),
+              ("fc1", 3072, 768, vithip.EPI_LNFOLD_GELU), ("fc2", 768, 3072, vithip.EPI_RESID_SPLIT)]
     dev = "cuda:0"
     print(f"{'shape':6s} {'N':>5s} {'K':>5s} | torch.matmul bf16 (no epilogue): us  TF | libvithip plain bias epilogue: us  TF | libvithip layer epilogue: us  TF")
     for name, N, K, epi in shapes:

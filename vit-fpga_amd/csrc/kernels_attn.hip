@@ -278,13 +278,10 @@ __device__ __forceinline__ void ring_barrier() {
 // One LDS-DMA instruction (64 lanes x 16 B -> 1 KiB at the LDS address in M0), written as inline asm on purpose: hipcc
 // makes every ds_read_b64_tr_b16 (an intrinsic without a memory operand) wait for vmcnt(0) while a global_load_lds
 // it knows of is in flight, which would drain the ring at every tile.  The kernel's own waits (ring_wait_dma) cover
-// the DMA; the compiler's vmcnt arithmetic for ordinary loads only gets stricter by not knowing these.
+// the DMA; the compiler's vmcnt arithmetic for ordinary loads only gets stricter by not knowing these.  The statement
+// itself, with the wait states its scalar operands need, lives in vh_common.h (asm_lds_dma16).
 __device__ __forceinline__ void ring_dma16(const void* base, uint32_t lane_off, uint32_t lds_addr) {
-    // s_nop 4: the base may have been reloaded into its SGPRs by v_readlane (SGPR spill) in the instruction before this
-    // statement; "VALU writes SGPR -> VMEM reads it" needs 5 wait states and the hazard recogniser does not look into
-    // inline asm (it also covers the one wait state between the M0 write and the LDS-DMA)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory", "m0");
+    asm_lds_dma16(base, lane_off, lds_addr);
 }
 #ifdef VH_DIAG_STAMPS
 // diagnostic build only (tools/attn_anatomy.py): per-wave shader-clock totals of the phases of the ring kernel
@@ -492,10 +489,9 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
         const bool refill = has_next && last_slab;            // the next item belongs to another head: stream its K/V in
         const elem* nbase = kv_base(has_next ? next : item);
         if (QS && dyn && has_next && wave == nw - 1 && lane == 0) {   // draw the ticket of the item after `next` (one lane)
-            const unsigned int one = 1u, zero = 0u;
-            // (s_nop 4: same SGPR-reload hazard as in ring_dma16 -- without it the atomic went out with a stale upper
-            //  address half and the launch died with a memory aperture violation)
-            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(tkv) : "v"(zero), "v"(one), "s"(ticket) : "memory");
+            // (vh_common.h: the statement opens with s_nop 4 -- without it the atomic went out with a stale upper address
+            //  half after an SGPR reload and the launch died with a memory aperture violation)
+            asm_atomic_add_ret_issue(ticket, 1u, tkv);
         }
         if (!(VH_ATTN_ABL & 2) && !first && slab == 0 && wave < 4) issue_tile(cbase, ntiles - 1);   // (a later slab finds the whole image in place)
         if (QS) {   // this wave's Q fragments out of the staging area (free again after the barrier at the top of tile 1)
@@ -706,30 +702,23 @@ template <typename T, typename TO = T>
 static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, unsigned int* ticket, hipStream_t s) {
     const int ntiles = (tokens + 31) / 32;
     const int nqb = ntiles;
-    static int max_waves = 0;   // waves per workgroup (each owns 32 queries): VH_ATTN_WAVES, default 16 (T = 577: 10 waves share one K/V image instead of 7)
-    if (!max_waves) { const char* e = getenv("VH_ATTN_WAVES"); max_waves = e ? atoi(e) : 16; if (max_waves < 1 || max_waves > 16) max_waves = 16; }
+    // waves per workgroup (each owns 32 queries): VH_ATTN_WAVES, default 16 (T = 577: 10 waves share one K/V image instead of 7)
+    static const int max_waves = [] { const int e = env_int("VH_ATTN_WAVES", 16); return e < 1 || e > 16 ? 16 : e; }();
     const int slabs = (nqb + max_waves - 1) / max_waves;
     const int nw = (nqb + slabs - 1) / slabs;
     const size_t one = attention_lds_bytes(tokens);
     if (one > 160 * 1024) return hipErrorInvalidValue;
     const int nitems = batch * heads * slabs;
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-        num_cu = prop.multiProcessorCount;
-    }
+    const int num_cu = device_num_cu();
+    if (!num_cu) return hipErrorUnknown;
     // persistent double-buffered form when two K/V images fit and there is more than one item per CU
     // VH_ATTN_PERSIST=1 selects it; measured slower at T=197 (7 waves/CU leave the softmax latency-bound), so
     // the default is the one-shot form with two workgroups per CU.
-    static int want_persist = -1;
-    if (want_persist < 0) { const char* e = getenv("VH_ATTN_PERSIST"); want_persist = e ? atoi(e) : 0; }
+    static const int want_persist = env_int("VH_ATTN_PERSIST", 0);
     const bool persist = want_persist && 2 * one <= 160 * 1024 && nitems > num_cu;
     // ring forms (default): need the four DMA waves and at least three key tiles; VH_ATTN_RING=0 selects the one-shot
     // form, 2 the ring without Q staging where the staged form would be used
-    static int want_ring = -1;
-    if (want_ring < 0) { const char* e = getenv("VH_ATTN_RING"); want_ring = e ? atoi(e) : 1; }
+    static const int want_ring = env_int("VH_ATTN_RING", 1);
     // staged-Q ring (counted waits): one slab of at least four waves whose trimmed images + staging fit twice in a CU
     const int G = (tokens + 7) / 8, G2 = (G + 1) & ~1;
     const size_t qs_lds = (size_t)(G + G2 + 4 * nw) * 1024 + 16;   // + the ticket word
@@ -737,11 +726,10 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     if constexpr (std::is_same<T, TO>::value)
     if (want_ring >= 1 && want_ring != 2 && slabs == 1 && nw >= 4 && 2 * qs_lds <= 160 * 1024) {
         auto k = attention_ring_kernel<T, TO, true>;
-        static int lds_done[kMaxDevices] = {0};
+        static LdsDone lds_done;
         if (hipError_t e = ensure_dynamic_lds((const void*)k, qs_lds, lds_done); e != hipSuccess) return e;
         const int grid = nitems < 2 * num_cu ? nitems : 2 * num_cu;
-        static int want_dyn = -1;   // VH_ATTN_DYN=0: equal static shares
-        if (want_dyn < 0) { const char* e = getenv("VH_ATTN_DYN"); want_dyn = e ? atoi(e) : 1; }
+        static const int want_dyn = env_int("VH_ATTN_DYN", 1);   // VH_ATTN_DYN=0: equal static shares
         unsigned int* tk = want_dyn && nw >= 5 && nitems > 2 * grid ? ticket : nullptr;
         if (tk) { if (hipError_t e = hipMemsetAsync(tk, 0, sizeof(unsigned int), s); e != hipSuccess) return e; }
         const unsigned int heads_rcp = (unsigned int)(((1ull << 32) + (unsigned)heads - 1) / (unsigned)heads);
@@ -751,7 +739,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     }
     if (want_ring && ntiles >= 3 && nw >= 4) {
         auto k = attention_ring_kernel<T, TO, false>;
-        static int lds_done[kMaxDevices] = {0};
+        static LdsDone lds_done;
         if (hipError_t e = ensure_dynamic_lds((const void*)k, one, lds_done); e != hipSuccess) return e;
         const int per_cu = (int)(160 * 1024 / one);       // co-resident workgroups per CU by LDS
         int grid = num_cu * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
@@ -762,7 +750,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     }
     if constexpr (!std::is_same<T, TO>::value) {
         auto k = attention_kernel<T, false, TO>;
-        static int lds_done[kMaxDevices] = {0};
+        static LdsDone lds_done;
         if (hipError_t e = ensure_dynamic_lds((const void*)k, one, lds_done); e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(nitems), dim3(nw * 64), one, s, (const typename T::elem*)qkv, (typename TO::elem*)out,
                            tokens, heads, slabs, ntiles, nitems);
@@ -771,7 +759,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     if (persist) {
         const size_t lds = 2 * one;
         auto k = attention_kernel<T, true>;
-        static int lds_done[kMaxDevices] = {0};
+        static LdsDone lds_done;
         if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
         const int per_cu = (int)(160 * 1024 / lds);   // co-resident workgroups per CU by LDS
         int grid = num_cu * (per_cu < 1 ? 1 : per_cu);
@@ -780,7 +768,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
                            tokens, heads, slabs, ntiles, nitems);
     } else {
         auto k = attention_kernel<T, false>;
-        static int lds_done[kMaxDevices] = {0};
+        static LdsDone lds_done;
         if (hipError_t e = ensure_dynamic_lds((const void*)k, one, lds_done); e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(nitems), dim3(nw * 64), one, s, (const typename T::elem*)qkv, (typename T::elem*)out,
                            tokens, heads, slabs, ntiles, nitems);

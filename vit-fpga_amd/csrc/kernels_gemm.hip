@@ -141,7 +141,7 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
     const int tiles_m = (int)((g.M + BM - 1) / BM), tiles_n = (g.N + BN - 1) / BN;
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
     auto k = gemm_nt_kernel<T, BM, BN, WM, WN, EPI>;
-    static int lds_done[kMaxDevices] = {0};  // per instantiation, per device
+    static LdsDone lds_done;  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, s,
                        (const typename T::elem*)g.a, (const typename T::elem*)g.w, g.bias, g.out,
@@ -183,21 +183,12 @@ static hipError_t launch_epi(const GemmArgs& g, int variant, hipStream_t s) {
 // range.  VH_GEMM_PP = 5 / 6 / 7 forces one form (A/B runs, tests).
 int gemm_pp_variant(int epilogue) {
     (void)epilogue;
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("VH_GEMM_PP");
-        v = e ? atoi(e) : 0;
-        if (v < 5 || v > 7) v = 0;
-    }
+    static const int v = [] { const int e = env_int("VH_GEMM_PP", 0); return e < 5 || e > 7 ? 0 : e; }();
     return v ? v : 6;
 }
 int gemm_pick_variant(int64_t M, int N, int epilogue) {
-    static int min_tiles = 0;
-    if (!min_tiles) {
-        const char* e = getenv("VH_PP_MIN_TILES");
-        min_tiles = e ? atoi(e) : 128;  // swept at batch 16..128 (ViT-B/16): 128 is best, +13 % at batch 64 over 256
-        if (min_tiles < 1) min_tiles = 1;
-    }
+    // swept at batch 16..128 (ViT-B/16): 128 is best, +13 % at batch 64 over 256
+    static const int min_tiles = [] { const int e = env_int("VH_PP_MIN_TILES", 128); return e < 1 ? 1 : e; }();
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
     return t256 >= min_tiles ? gemm_pp_variant(epilogue) : 1;  // the 256x256 ping-pong kernel needs enough tiles for the 256 CUs
 }

@@ -427,23 +427,58 @@ hipError_t launch_layernorm_split(const void* hi, const void* lo, int64_t rows, 
 
 // partials [nblk][rows][2] = (sum, sum of squares) over 64-column blocks -> stats [rows][2] = (mean, rstd).
 // Fixed summation order (block 0, 1, ...) keeps the result independent of how the producing tiles were scheduled.
-__global__ void __launch_bounds__(256)
-finalize_stats_kernel(const float* __restrict__ partials, int nblk, int64_t rows, int dim, float eps, float* __restrict__ stats) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        const float2 p = *(const float2*)(partials + 2 * ((int64_t)b * rows + r));
-        s1 += p.x;
-        s2 += p.y;
-    }
-    const float mean = s1 / (float)dim;
-    const float var = fmaxf(s2 / (float)dim - mean * mean, 0.f);
-    *(float2*)(stats + 2 * r) = make_float2(mean, 1.0f / sqrtf(var + eps));
+// `guard` (optional): the run-time check on the folded LayerNorm.  The folded GEMM multiplies the rounded
+// UNCENTRED rows, so its rounding error relative to the centred signal grows with sqrt(1 + (mean/sigma)^2); every row of
+// the first `guard_rows` rows (the real ones: rows behind them are tile padding) contributes |mean| * rstd to a running
+// maximum kept as the bits of a non-negative float (ordered like unsigned integers; a NaN ranks above everything and
+// trips the guard too).  One atomic per wave.
+__device__ __forceinline__ void ln_guard_update(float ratio, unsigned int* guard) {
+    unsigned int b = __float_as_uint(ratio) & 0x7FFFFFFFu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)b, o); b = t > b ? t : b; }
+    if ((threadIdx.x & 63) == 0 && b) atomicMax(guard, b);
 }
-hipError_t launch_finalize_stats(const float* partials, int nblk, int64_t rows, int dim, float eps, float* stats, hipStream_t s) {
+__global__ void __launch_bounds__(256)
+finalize_stats_kernel(const float* __restrict__ partials, int nblk, int64_t rows, int dim, float eps, float* __restrict__ stats,
+                      int64_t guard_rows, unsigned int* __restrict__ guard) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float ratio = 0.f;
+    if (r < rows) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int b = 0; b < nblk; ++b) {
+            const float2 p = *(const float2*)(partials + 2 * ((int64_t)b * rows + r));
+            s1 += p.x;
+            s2 += p.y;
+        }
+        const float mean = s1 / (float)dim;
+        const float var = fmaxf(s2 / (float)dim - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        *(float2*)(stats + 2 * r) = make_float2(mean, rstd);
+        if (r < guard_rows) ratio = fabsf(mean) * rstd;
+    }
+    if (guard) ln_guard_update(ratio, guard);   // (whole waves reach this: no early return above)
+}
+hipError_t launch_finalize_stats(const float* partials, int nblk, int64_t rows, int dim, float eps, float* stats, hipStream_t s,
+                                 int64_t guard_rows, unsigned int* guard) {
     if (rows <= 0 || nblk <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, nblk, rows, dim, eps, stats);
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, nblk, rows, dim, eps, stats,
+                       guard_rows, guard);
+    return hipGetLastError();
+}
+// the same check on statistics that already exist (layer 0: written by the rowstats kernels)
+__global__ void __launch_bounds__(256)
+ln_guard_kernel(const float* __restrict__ stats, int64_t rows, unsigned int* __restrict__ guard) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float ratio = 0.f;
+    if (r < rows) {
+        const float2 st = *(const float2*)(stats + 2 * r);
+        ratio = fabsf(st.x) * st.y;
+    }
+    ln_guard_update(ratio, guard);
+}
+hipError_t launch_ln_guard(const float* stats, int64_t rows, unsigned int* guard, hipStream_t s) {
+    if (rows <= 0 || !guard) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_guard_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, stats, rows, guard);
     return hipGetLastError();
 }
 

@@ -97,6 +97,38 @@ __device__ __forceinline__ f32x4 pack4<F32OUT>(float a, float b, float c, float 
     return f32x4{a, b, c, d};
 }
 
+// ---- inline-asm vector-memory instructions with scalar operands: ONE place for the hazard rule --------------------------
+// hipcc's hazard recogniser does not look into an asm string.  A scalar operand ("s") of a VMEM instruction inside one may
+// have been written by a VALU instruction immediately in front of the statement -- v_readlane / v_readfirstlane when the
+// register allocator reloads a spilled SGPR pair -- and "VALU writes SGPR -> VMEM reads that SGPR" needs 5 wait states.
+// Without them the instruction goes out with a stale register half (round 2: an atomic with a stale upper address half,
+// memory aperture violation).  Every asm VMEM instruction of this library that takes an "s" operand is therefore issued
+// through one of the helpers below, whose strings open with `s_nop 4` (it also covers the wait state between an M0 write
+// and the LDS-DMA that reads M0).
+//
+// One LDS-DMA instruction: 64 lanes x 16 B from `base + lane_off` -> 1 KiB at LDS byte address `lds_addr` (lane-linear).
+// Written as asm on purpose where the compiler must NOT know about the transfer: hipcc answers an LDS read that may alias
+// a global_load_lds it knows of with s_waitcnt vmcnt(0), which drains every DMA in flight.  The caller owns the
+// vmcnt / barrier bookkeeping that orders the ds_read behind the transfer.
+__device__ __forceinline__ void asm_lds_dma16(const void* base, uint32_t lane_off, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory", "m0");
+}
+// The same for a kernel in which the COMPILER also issues LDS-DMA (__builtin_amdgcn_global_load_lds): M0 is
+// compiler-managed there and an "m0" clobber is not honoured, so the statement saves and restores it.
+__device__ __forceinline__ void asm_lds_dma16_keep_m0(const void* base, uint32_t lane_off, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(lane_off), "s"(base) : "memory");
+}
+// Returning atomic add on the wave-uniform address `base`, ISSUE only: `ret` is written when the operation completes,
+// i.e. the caller waits (vmcnt) before the first use of `ret` and keeps `ret`'s register untouched until then (the
+// attention work queue draws its ticket this way, one lane active).
+__device__ __forceinline__ void asm_atomic_add_ret_issue(unsigned int* base, uint32_t add, uint32_t& ret) {
+    const uint32_t zero = 0;
+    asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(ret) : "v"(zero), "v"(add), "s"(base) : "memory");
+}
+
 __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }

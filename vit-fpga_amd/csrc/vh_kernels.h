@@ -1,6 +1,9 @@
 // vh_kernels.h — internal launch API between the C-ABI layer (vithip_api.hip) and the kernels.
 #pragma once
 
+#include <atomic>
+#include <cstdlib>
+
 #include "vh_common.h"
 
 namespace vh {
@@ -74,8 +77,10 @@ hipError_t launch_permute_patch(const float* w_nchw, int dim, int channels, int 
 // folded LayerNorm helpers
 hipError_t launch_rowstats_cast(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, int dtype,
                                 hipStream_t stream);
+// guard (optional): running maximum of |mean| * rstd over the first `guard_rows` rows, as float bits (kernels_misc.hip)
 hipError_t launch_finalize_stats(const float* partials, int nblk, int64_t rows, int dim, float eps, float* stats,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int64_t guard_rows = 0, unsigned int* guard = nullptr);
+hipError_t launch_ln_guard(const float* stats, int64_t rows, unsigned int* guard, hipStream_t stream);
 // split residual (x = hi + lo, two 16-bit planes; gemm_epilogue.h RESID_SPLIT): fp32 rows -> planes + row statistics, and
 // the fp32 LayerNorm of selected rows (the CLS rows) of the planes
 hipError_t launch_rowstats_split(const float* x, int64_t rows, int dim, float eps, void* hi, void* lo, float* stats, int dtype,
@@ -94,17 +99,37 @@ hipError_t launch_dense_layer(const float* w, const float* b, const float* x, fl
 // 3x3 filter on 8-bit frames (filter_image): kind 0 = binomial blur, 1 = Sobel |gx|+|gy|
 hipError_t launch_filter3x3(const uint8_t* in, uint8_t* out, int h, int w, int kind, hipStream_t stream);
 
-// Opt a kernel in to `bytes` of dynamic LDS on the CURRENT device.  The attribute is per device, so the record of
-// what has been set is too: `done[d]` = bytes already granted on device d (one array per kernel instantiation).
+// ---- launcher-side caches: reached concurrently from the device-group member threads (vh_group_*, one host thread per
+// device), so none of them is a plain static.  Environment knobs are function-local `static const` values (C++11: the
+// initialiser runs exactly once, other threads wait for it); per-device facts are tables of relaxed atomics indexed by
+// the device ordinal (every writer stores the same value).
 constexpr int kMaxDevices = 64;
-inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, int (&done)[kMaxDevices]) {
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+// number of CUs of the CURRENT device (0 on error)
+inline int device_num_cu() {
+    static std::atomic<int> table[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    int n = table[dev].load(std::memory_order_relaxed);
+    if (n) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+    table[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+// Opt a kernel in to `bytes` of dynamic LDS on the CURRENT device.  The attribute is per device, so the record of
+// what has been set is too: `done[d]` = bytes already granted on device d (one table per kernel instantiation).
+using LdsDone = std::atomic<int>[kMaxDevices];
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, LdsDone& done) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
-    if ((size_t)done[dev] >= bytes) return hipSuccess;
+    if ((size_t)done[dev].load(std::memory_order_acquire) >= bytes) return hipSuccess;
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) done[dev] = (int)bytes;
+    if (e == hipSuccess) done[dev].store((int)bytes, std::memory_order_release);
     return e;
 }
 

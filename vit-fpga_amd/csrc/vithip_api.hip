@@ -175,6 +175,18 @@ struct vh_ctx {
     // VH_RESID_SPLIT=0 (A/B tools) keeps the fp32 array.
     bool split = false;
     void* xlo16 = nullptr;    // [B*T, D]
+    // Run-time guard on the fold: the kernels that produce the row statistics keep a running maximum of
+    // |mean| * rstd over the REAL rows (guard_dev: the bits of a non-negative float); every forward ends with an
+    // asynchronous copy of that word into pinned host memory, and every forward entry point looks at the copy before it
+    // enqueues anything (no synchronisation: the value is the one of the most recently COMPLETED forward).  Beyond
+    // guard_thresh the folded operand's rounding error leaves the budget of the 1e-3 tolerance; a context whose flags
+    // left the choice to the library (guard_auto) then switches to the stand-alone LayerNorm for good -- the weights are
+    // prepared again in the plain layout -- and the synchronous vh_forward repeats the forward that tripped it.
+    bool ln_fold_cfg = false, split_cfg = false;   // what configuration + flags chose at creation (restored by a weight load)
+    unsigned int* guard_dev = nullptr;
+    float* guard_host = nullptr;
+    float guard_thresh = 0.5f;
+    bool guard_auto = false, guard_tripped = false;
     // activations (sized for max_batch)
     char* arena = nullptr;
     unsigned int* tickets = nullptr;   // [max_batch] work-queue counters of the attention kernel (launch_attention)
@@ -203,6 +215,7 @@ struct vh_ctx {
     hipStream_t tstream = nullptr;
     hipEvent_t ev_tail_a = nullptr, ev_tail_l = nullptr;
     bool tail_overlap = false;
+    int tail_splits = 0;   // residual GEMMs of the last forward that were launched as [full rounds] + [tail round] (debug tap 2)
     int num_cu = 256;
     // optional hipGraph replay of the forward's launch sequence (vh_set_graph): one instantiated graph per
     // (input pointer, logits pointer, batch); a batch size runs eagerly once before it is captured
@@ -214,6 +227,10 @@ struct vh_ctx {
     int timing_stage = -1;
     std::vector<hipEvent_t> tev;  // pool: pairs (start, stop)
     size_t tev_used = 0;
+    // optional per-STEP events of the last vh_forward_device_async call (vh_set_step_timing): K + 1 boundaries
+    bool step_timing = false;
+    std::vector<hipEvent_t> sev;
+    size_t sev_used = 0;
     std::string err;
 };
 
@@ -336,6 +353,17 @@ int prepare_weights(vh_ctx* c) {
     return VH_OK;
 }
 
+// new weights: the guard starts over and the path is the configured one again
+int guard_reset(vh_ctx* c) {
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));   // no forward in flight still writes the word
+    HIPCHK(&c->err, hipMemsetAsync(c->guard_dev, 0, sizeof(unsigned int), c->stream));
+    *c->guard_host = 0.f;
+    c->guard_tripped = false;
+    c->ln_fold = c->ln_fold_cfg;
+    c->split = c->split_cfg;
+    return VH_OK;
+}
+
 int check_blob_header(vh_ctx* c, const BlobHeader& h) {
     const vh_config& f = c->cfg;
     if (memcmp(h.magic, "VHBLOB1", 8) != 0) return fail(&c->err, VH_ERR_INVALID, "weight blob: bad magic");
@@ -414,6 +442,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         return VH_OK;
     };
     int rc;
+    if (img0 == 0) c->tail_splits = 0;
     if ((rc = mark(-1))) return rc;
     HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, col16, dt16, s));
     if ((rc = mark(ST_IM2COL))) return rc;
@@ -426,6 +455,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
         if (c->split) HIPCHK(&c->err, launch_rowstats_split(x, rows_g, D, f.ln_eps, xn16, xlo16, stats_p, dt16, s));
         else HIPCHK(&c->err, launch_rowstats_cast(x, rows_g, D, f.ln_eps, xn16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s));
+        HIPCHK(&c->err, launch_ln_guard(stats_p, rows, c->guard_dev, s));   // real rows only (rows_g - rows are tile padding)
         if ((rc = mark(ST_LNSTATS))) return rc;
     }
     for (int l = 0; l < nl && c->ln_fold; ++l) {
@@ -447,7 +477,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         else HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows_g, D, D, VH_EPI_RESID_LN, nullptr, 0, so));
         if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
-        HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows_g, D, f.ln_eps, stats_p, s));
+        HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev));
         if ((rc = mark(ST_LNSTATS))) return rc;
         if ((rc = tmark(ST_FC1))) return rc;
         HIPCHK(&c->err, gemm(xn16, c->w1_16[l], cd + 6 * D + M, h16, rows_g, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0, s1));
@@ -459,7 +489,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
         if (l + 1 < nl) {
-            HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows_g, D, f.ln_eps, stats_p, s));
+            HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev));
             if ((rc = mark(ST_LNSTATS))) return rc;
         }
     }
@@ -471,6 +501,8 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         GemmArgs g{a, w, bias, out, rows, N, K, epi, c->fp8 ? scale : nullptr, 0, op_dt, 0};
         g.tile_begin = tile_begin;
         g.tile_count = tile_count;
+        // a range of tiles exists in the one-tile-per-workgroup forms only: the persistent default (6) hands it to form 5
+        if ((tile_begin || tile_count) && !c->fp8) g.variant = gemm_pick_variant(rows, N, epi) == 7 ? 7 : 5;
         return c->fp8 ? launch_gemm_fp8(g, s) : launch_gemm(g, s);
     };
     auto ln_rows = [&](int64_t r_begin, int64_t r_count, const float* w, const float* b, hipStream_t st) {
@@ -485,7 +517,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
                              const float* lnb, int st_gemm) -> int {
         const int tiles_n = (D + 255) / 256, ntile = (int)((rows + 255) / 256) * tiles_n;
         int split = 0;
-        const bool pp = c->fp8 || gemm_pick_variant(rows, D, VH_EPI_BIAS_RESID) == 5 || gemm_pick_variant(rows, D, VH_EPI_BIAS_RESID) == 7;
+        const bool pp = c->fp8 || gemm_pick_variant(rows, D, VH_EPI_BIAS_RESID) >= 5;   // any 256x256 ping-pong form (5, 6, 7)
         if (allow_tail && c->tail_overlap && lnw && !ev && pp && ntile > c->num_cu && ntile % c->num_cu != 0 &&
             c->timing_stage != ST_LN && c->timing_stage != ST_PROJ && c->timing_stage != ST_FC2) {
             split = ntile / c->num_cu * c->num_cu;
@@ -503,6 +535,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
             if ((r = tmark(ST_LN))) return r;
             return mark(ST_LN);
         }
+        ++c->tail_splits;
         const int64_t rows_a = (int64_t)(split / tiles_n) * 256;
         HIPCHK(&c->err, gemm_any(a, w, bias, scale, x, D, K, VH_EPI_BIAS_RESID, 0, split));
         HIPCHK(&c->err, hipEventRecord(c->ev_tail_a, s));
@@ -553,6 +586,27 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     return VH_OK;
 }
 
+// end of a forward: the guard word travels to pinned host memory behind the forward's kernels (stream order)
+int guard_publish(vh_ctx* c) {
+    if (c->ln_fold) HIPCHK(&c->err, hipMemcpyAsync(c->guard_host, c->guard_dev, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return VH_OK;
+}
+// top of every forward entry point: has a COMPLETED forward seen rows beyond the guard's threshold?  (NaN trips it too.)
+bool guard_exceeded(const vh_ctx* c) {
+    return c->ln_fold && c->guard_host && !(*(volatile const float*)c->guard_host <= c->guard_thresh);
+}
+int prepare_weights(vh_ctx* c);
+void drop_graphs(vh_ctx* c);
+int guard_poll(vh_ctx* c) {
+    if (!guard_exceeded(c)) return VH_OK;
+    c->guard_tripped = true;
+    if (!c->guard_auto) return VH_OK;   // VH_FLAG_LN_FOLD_ON: the caller's explicit choice stands; vh_get_ln_guard reports
+    c->ln_fold = false;
+    c->split = false;
+    drop_graphs(c);
+    return prepare_weights(c);          // the plain (unfolded) 16-bit / e4m3 weights, from the resident blob
+}
+
 // one complete forward of `batch` images on the context's stream(s): the (optional) concurrent parts are forked
 // from and joined back into c->stream, so everything that follows on c->stream sees the finished logits
 int enqueue_step(vh_ctx* c, const float* in, int batch, float* logits) {
@@ -578,9 +632,10 @@ int enqueue_step(vh_ctx* c, const float* in, int batch, float* logits) {
             b0 += nb;
         }
         c->last_batch = batch;
-        return VH_OK;
+        return guard_publish(c);
     }
-    return enqueue_forward(c, in, batch, logits, nullptr, c->stream, 0, true);
+    if ((rc = enqueue_forward(c, in, batch, logits, nullptr, c->stream, 0, true))) return rc;
+    return guard_publish(c);
 }
 
 void drop_graphs(vh_ctx* c) {
@@ -594,6 +649,7 @@ void drop_graphs(vh_ctx* c) {
 // enqueue_step, or the replay of its captured launch sequence.  Small batches are launch-bound (ViT-B/16 at
 // batch 1: ~100 launches, 1.27 ms eager): the graph removes the per-launch API cost and the gaps between kernels.
 int run_step(vh_ctx* c, const float* in, int batch, float* logits) {
+    if (int rc = guard_poll(c)) return rc;
     if (!c->use_graph || c->timing_stage >= 0) return enqueue_step(c, in, batch, logits);
     for (auto& g : c->graphs)
         if (g.in == in && g.out == logits && g.batch == batch) {
@@ -771,6 +827,9 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         if (cfg->flags & VH_FLAG_LN_FOLD_OFF) want = false;
         else if (!(cfg->flags & VH_FLAG_LN_FOLD_ON)) { const char* e = getenv("VH_LN_FOLD"); if (e) want = e[0] == '1'; }
         c->ln_fold = eligible && want;
+        // the library's own default (no flag, no VH_LN_FOLD in the environment) is the GUARDED fold
+        c->guard_auto = c->ln_fold && !(cfg->flags & (VH_FLAG_LN_FOLD_ON | VH_FLAG_LN_FOLD_OFF)) && !getenv("VH_LN_FOLD");
+        if (const char* e = getenv("VH_LN_GUARD")) { const float t = (float)atof(e); if (t > 0.f) c->guard_thresh = t; }
     }
     c->fp8 = cfg->dtype == VH_DTYPE_FP8;
     c->dt16 = c->fp8 ? VH_DTYPE_BF16 : cfg->dtype;
@@ -778,7 +837,11 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         // (fp8 operands: the fold runs on an e4m3 copy of the raw rows and keeps the fp32 residual -- no split planes)
         const char* e = getenv("VH_RESID_SPLIT");
         c->split = c->ln_fold && !c->fp8 && !(e && e[0] == '0');
+        c->ln_fold_cfg = c->ln_fold;
+        c->split_cfg = c->split;
     }
+    CK(hipHostMalloc((void**)&c->guard_host, 64, hipHostMallocDefault));
+    *c->guard_host = 0.f;
     const size_t o_cd = w16_bytes;
     w16_bytes += align_up((size_t)cfg->layers * (6 * D + 2 * M) * 4, 256);
     const size_t o_sc = w16_bytes, sc_per_layer = 5 * D + M;  // fp8: scales of q|k|v (3D), o (D), fc1 (M), fc2 (D)
@@ -805,8 +868,11 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
                  o_cls = carve(B * D * 4),
                  o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4),
                  o_st = carve(rows_p * 2 * 4), o_pt = carve((D / 64 + 1) * rows_p * 2 * 4), o_xlo = carve(rows_p * D * 2),
-                 o_tk = carve(B * 4);   // attention work-queue counters: one word per image, a part uses its first image's
+                 o_tk = carve(B * 4),   // attention work-queue counters: one word per image, a part uses its first image's
+                 o_gd = carve(256);     // the LayerNorm-fold guard word
     CK(hipMalloc((void**)&c->arena, a));
+    c->guard_dev = (unsigned int*)(c->arena + o_gd);
+    CK(hipMemsetAsync(c->guard_dev, 0, 256, c->stream));
     c->x = (float*)(c->arena + o_x); c->xn16 = c->arena + o_xn; c->qkv16 = c->arena + o_qkvA; c->att16 = c->arena + o_att;
     c->h16 = c->arena + o_h; c->col16 = c->arena + o_col; c->clsn32 = (float*)(c->arena + o_cls);
     c->in_dev = (float*)(c->arena + o_in); c->logits_dev = (float*)(c->arena + o_lg);
@@ -823,10 +889,12 @@ int vh_destroy(vh_ctx* c) {
     vh_ring_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     drop_graphs(c);
+    if (c->guard_host) hipHostFree(c->guard_host);
     if (c->arena) hipFree(c->arena);
     if (c->w16) hipFree(c->w16);
     if (c->blob) hipFree(c->blob);
     for (hipEvent_t e : c->tev) hipEventDestroy(e);
+    for (hipEvent_t e : c->sev) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (int i = 0; i < vh_ctx::kMaxStreams - 1; ++i) {
@@ -854,6 +922,19 @@ int vh_get_ln_fold(const vh_ctx* c, int* on) {
     return VH_OK;
 }
 
+int vh_get_ln_guard(vh_ctx* c, float* max_ratio, float* threshold, int* tripped) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    float seen = 0.f;
+    HIPCHK(&c->err, hipMemcpy(&seen, c->guard_dev, sizeof seen, hipMemcpyDeviceToHost));
+    if (!(seen <= c->guard_thresh) && c->ln_fold_cfg) c->guard_tripped = true;
+    if (max_ratio) *max_ratio = seen;
+    if (threshold) *threshold = c->guard_thresh;
+    if (tripped) *tripped = c->guard_tripped ? 1 : 0;
+    return VH_OK;
+}
+
 int vh_load_weights(vh_ctx* c, const void* host_blob, size_t nbytes) {
     if (!c || !host_blob) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "vh_load_weights: null argument");
     const size_t need = sizeof(BlobHeader) + 4 * c->L.total;
@@ -865,6 +946,7 @@ int vh_load_weights(vh_ctx* c, const void* host_blob, size_t nbytes) {
     HIPCHK(&c->err, hipSetDevice(c->device));
     c->weights_ready = false;
     HIPCHK(&c->err, hipMemcpyAsync(c->blob, host_blob, nbytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = guard_reset(c))) return rc;
     return prepare_weights(c);
 }
 
@@ -879,6 +961,7 @@ int vh_load_weights_device(vh_ctx* c, const void* dev_blob, size_t nbytes) {
     if (rc) return rc;
     c->weights_ready = false;
     if (dev_blob != c->blob) HIPCHK(&c->err, hipMemcpyAsync(c->blob, dev_blob, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = guard_reset(c))) return rc;
     return prepare_weights(c);
 }
 
@@ -918,6 +1001,7 @@ int vh_init_weights_seeded(vh_ctx* c, uint64_t seed) {
     GEN(L.lnfw, D, TID_FINAL + 0, sg, 1.f); GEN(L.lnfb, D, TID_FINAL + 1, sb, 0.f);
     GEN(L.headw, C * D, TID_FINAL + 2, sw, 0.f); GEN(L.headb, C, TID_FINAL + 3, sb, 0.f);
 #undef GEN
+    if (int rc = guard_reset(c)) return rc;
     return prepare_weights(c);
 }
 
@@ -1050,9 +1134,23 @@ int vh_forward_device_async(vh_ctx* c, const float* in, int batch, float* logits
     if (steps <= 0) return fail(&c->err, VH_ERR_INVALID, "steps must be positive");
     HIPCHK(&c->err, hipSetDevice(c->device));
     c->tev_used = 0;
+    c->sev_used = 0;
+    auto step_mark = [&]() -> int {
+        if (!c->step_timing) return VH_OK;
+        if (c->sev_used == c->sev.size()) {
+            hipEvent_t e;
+            HIPCHK(&c->err, hipEventCreate(&e));
+            c->sev.push_back(e);
+        }
+        HIPCHK(&c->err, hipEventRecord(c->sev[c->sev_used++], c->stream));
+        return VH_OK;
+    };
     HIPCHK(&c->err, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < steps; ++i)
+    if ((rc = step_mark())) return rc;
+    for (int i = 0; i < steps; ++i) {
         if ((rc = run_step(c, in, batch, logits))) return rc;
+        if ((rc = step_mark())) return rc;
+    }
     HIPCHK(&c->err, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return VH_OK;
@@ -1088,6 +1186,13 @@ int vh_forward(vh_ctx* c, const float* in_host, int batch, float* logits_host) {
     if (rc) return rc;
     HIPCHK(&c->err, hipMemcpyAsync(logits_host, c->logits_dev, (size_t)batch * f.classes * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    if (c->guard_auto && guard_exceeded(c)) {
+        // this (synchronous) forward itself ran folded on rows beyond the guard: run it again, now with the stand-alone LayerNorm
+        rc = vh_forward_device_async(c, c->in_dev, batch, c->logits_dev, 1);   // (its run_step polls the guard and switches)
+        if (rc) return rc;
+        HIPCHK(&c->err, hipMemcpyAsync(logits_host, c->logits_dev, (size_t)batch * f.classes * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    }
     c->last_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
     return VH_OK;
 }
@@ -1311,6 +1416,28 @@ int vh_get_stage_timing(vh_ctx* c, double* avg_ms, double* min_ms, int* launches
     return VH_OK;
 }
 
+int vh_set_step_timing(vh_ctx* c, int enable) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    c->step_timing = enable != 0;
+    c->sev_used = 0;
+    return VH_OK;
+}
+
+int vh_get_step_timing(vh_ctx* c, double* step_ms, int max_steps, int* steps) {
+    if (!c || !steps || (max_steps > 0 && !step_ms)) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    int n = 0;
+    for (size_t i = 0; i + 1 < c->sev_used; ++i) {
+        float t = 0.f;
+        HIPCHK(&c->err, hipEventElapsedTime(&t, c->sev[i], c->sev[i + 1]));
+        if (n < max_steps) step_ms[n] = t;
+        ++n;
+    }
+    *steps = n;
+    return VH_OK;
+}
+
 int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
     if (!c || !host_out) return fail(c ? &c->err : nullptr, VH_ERR_INVALID, "null argument");
     if (c->last_batch <= 0) return fail(&c->err, VH_ERR_STATE, "no forward has run");
@@ -1339,6 +1466,11 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
         const size_t n = (size_t)c->last_batch * D;
         if (n_floats != n) return fail(&c->err, VH_ERR_INVALID, "expected %zu floats", n);
         HIPCHK(&c->err, hipMemcpy(host_out, c->clsn32, n * 4, hipMemcpyDeviceToHost));
+        return VH_OK;
+    }
+    if (what == 2) {   // how many residual GEMMs of the last forward ran as a split launch (VH_TAIL_OVERLAP)
+        if (n_floats != 1) return fail(&c->err, VH_ERR_INVALID, "expected 1 float");
+        host_out[0] = (float)c->tail_splits;
         return VH_OK;
     }
     return fail(&c->err, VH_ERR_INVALID, "unknown tap %d", what);
@@ -1429,14 +1561,14 @@ int vh_op_attention(const void* qkv16, int batch, int tokens, int heads, void* o
     if (!qkv16 || !out16) return fail(nullptr, VH_ERR_INVALID, "null pointer");
     if (batch <= 0 || tokens <= 0 || heads <= 0 || attention_lds_bytes(tokens) > 160 * 1024)
         return fail(nullptr, VH_ERR_INVALID, "attention: unsupported shape");
-    // the operator tap owns one counter per device (taps run one at a time; a context carries its own in its arena)
-    static unsigned int* tap_ticket[kMaxDevices] = {nullptr};
-    int dev = 0;
-    OPCHK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kMaxDevices) return fail(nullptr, VH_ERR_INVALID, "attention: device ordinal out of range");
-    if (!tap_ticket[dev]) OPCHK(hipMalloc((void**)&tap_ticket[dev], 256));
-    OPCHK(launch_attention(qkv16, batch, tokens, heads, out16, dtype, tap_ticket[dev], (hipStream_t)stream));
-    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    // The work-queue counter is owned by THIS call (allocated, used, freed): taps may run concurrently from several host
+    // threads, and a context carries its own counters in its arena.
+    unsigned int* ticket = nullptr;
+    OPCHK(hipMalloc((void**)&ticket, 256));
+    hipError_t e = launch_attention(qkv16, batch, tokens, heads, out16, dtype, ticket, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(ticket);
+    if (e != hipSuccess) return fail(nullptr, VH_ERR_HIP, "attention failed: %s", hipGetErrorString(e));
     return VH_OK;
 }
 int vh_op_im2col(const float* in, int batch, int image, int patch, int channels, void* out16, int dtype, void* stream) {
@@ -1466,13 +1598,18 @@ int vh_bench_gemm(int device, int64_t M, int N, int K, int epilogue, int dtype, 
     if (!avg_ms || iters <= 0) return fail(nullptr, VH_ERR_INVALID, "vh_bench_gemm: bad argument");
     int rc = set_device(nullptr, device);
     if (rc) return rc;
-    float *a32 = nullptr, *w32 = nullptr, *bias = nullptr, *aux = nullptr;
-    void *a16 = nullptr, *w16 = nullptr, *out = nullptr;
+    float *a32 = nullptr, *w32 = nullptr, *bias = nullptr, *aux = nullptr, *stats = nullptr, *partials = nullptr;
+    void *a16 = nullptr, *w16 = nullptr, *out = nullptr, *out16 = nullptr;
     const int aux_i = 196;
+    // the layer epilogues of the folded path: LNFOLD* read per-row (mean, rstd) and c_n (`aux`), RESID_LN / RESID_SPLIT
+    // write a second 16-bit plane and the per-64-column row sums
+    const bool fold = epilogue == VH_EPI_LNFOLD || epilogue == VH_EPI_LNFOLD_GELU;
+    const bool resid2 = epilogue == VH_EPI_RESID_LN || epilogue == VH_EPI_RESID_SPLIT;
     const size_t out_rows = epilogue == VH_EPI_PATCH ? (size_t)(M / aux_i + 1) * (aux_i + 1) : (size_t)M;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
         hipFree(a32); hipFree(w32); hipFree(bias); hipFree(aux); hipFree(a16); hipFree(w16); hipFree(out);
+        hipFree(stats); hipFree(partials); hipFree(out16);
         if (e0) hipEventDestroy(e0);
         if (e1) hipEventDestroy(e1);
     };
@@ -1492,6 +1629,18 @@ int vh_bench_gemm(int device, int64_t M, int N, int K, int epilogue, int dtype, 
     BCHK(launch_cast(a32, a16, (int64_t)M * K, dtype, nullptr));
     BCHK(launch_cast(w32, w16, (int64_t)N * K, dtype, nullptr));
     GemmArgs g{a16, w16, bias, out, M, N, K, epilogue, aux, aux_i, dtype, variant};
+    if (fold) {   // (mean, rstd) ~ (0.02 sigma, 1 + 0.02 sigma): the values do not matter for the time
+        BCHK(hipMalloc((void**)&stats, (size_t)M * 2 * 4));
+        BCHK(launch_fill(stats, (int64_t)M * 2, 1, 5, 1, 0.02f, 0.f, nullptr));
+        g.stats = stats;
+    }
+    if (resid2) {
+        BCHK(hipMalloc(&out16, (size_t)M * N * 2));
+        BCHK(hipMemset(out16, 0, (size_t)M * N * 2));
+        BCHK(hipMalloc((void**)&partials, (size_t)((N + 63) / 64) * M * 2 * 4));
+        g.out16 = out16;
+        g.partials = partials;
+    }
     if (const char* why = gemm_check(g)) { cleanup(); return fail(nullptr, VH_ERR_INVALID, "%s", why); }
     BCHK(hipEventCreate(&e0));
     BCHK(hipEventCreate(&e1));
@@ -1843,6 +1992,10 @@ int vh_group_create(const vh_config* cfg, const int* devices, int n, vh_group** 
         g->m.push_back(std::move(m));
         if (rc != VH_OK) { vh_group_destroy(g); return rc; }
     }
+    // RCCL serves groups of DISTINCT devices only (a communicator cannot hold one device twice): a group that lists an
+    // ordinal more than once -- the one-GPU rehearsal of the N > 1 code path -- always broadcasts by device-to-device copy.
+    // VH_GROUP_FORCE_RCCL=1 makes a group of ONE go through ncclCommInitAll / ncclBroadcast as well (a smoke test of the
+    // run-time binding); it has no effect on a rehearsal group.
     const char* force = getenv("VH_GROUP_FORCE_RCCL");
     if ((n > 1 && !g->same_device) || (force && force[0] == '1' && !g->same_device)) {
         int rc = bind_rccl(g);
@@ -1883,13 +2036,18 @@ int vh_group_broadcast_weights(vh_group* g) {
     if (!g->comms.empty()) {
         HIPCHK(&g->err, hipSetDevice(g->m[0]->device));
         HIPCHK(&g->err, hipStreamSynchronize(root->stream));
+        // Whatever fails between GroupStart and GroupEnd, the group is still ENDED before this function returns: leaving it
+        // open would leave the other members' streams with a half-enqueued collective.
         int r = g_rccl.GroupStart();
-        for (int i = 0; i < n && r == 0; ++i) {
-            HIPCHK(&g->err, hipSetDevice(g->m[i]->device));
+        hipError_t he = hipSuccess;
+        for (int i = 0; i < n && r == 0 && he == hipSuccess; ++i) {
+            he = hipSetDevice(g->m[i]->device);
+            if (he != hipSuccess) break;
             vh_ctx* c = g->m[i]->ctx;
             r = g_rccl.Broadcast(root->blob, c->blob, nbytes, /*ncclUint8*/ 1, 0, g->comms[i], c->stream);
         }
         const int r2 = g_rccl.GroupEnd();
+        if (he != hipSuccess) return fail(&g->err, VH_ERR_HIP, "vh_group_broadcast_weights: hipSetDevice: %s", hipGetErrorString(he));
         if (r == 0) r = r2;
         if (r != 0) return fail(&g->err, VH_ERR_HIP, "ncclBroadcast: %s", g_rccl.GetErrorString(r));
         for (int i = 0; i < n; ++i) {

@@ -52,6 +52,7 @@ SYMBOLS = {
     "vh_destroy": (_i, [_vp]),
     "vh_get_config": (_i, [_vp, C.POINTER(Config)]),
     "vh_get_ln_fold": (_i, [_vp, _pi]),
+    "vh_get_ln_guard": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), _pi]),
     "vh_weight_blob_bytes": (_sz, [C.POINTER(Config)]),
     "vh_load_weights": (_i, [_vp, _vp, _sz]),
     "vh_load_weights_device": (_i, [_vp, _vp, _sz]),
@@ -90,6 +91,8 @@ SYMBOLS = {
     "vh_get_streams": (_i, [_vp, _pi]),
     "vh_set_stage_timing": (_i, [_vp, _i]),
     "vh_get_stage_timing": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _pi]),
+    "vh_set_step_timing": (_i, [_vp, _i]),
+    "vh_get_step_timing": (_i, [_vp, C.POINTER(C.c_double), _i, _pi]),
     "vh_debug_read": (_i, [_vp, _i, _vp, _sz]),
     "vh_debug_set_layers": (_i, [_vp, _i]),
     "vh_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp]),
@@ -304,6 +307,12 @@ class VitContext:
         _check(lib().vh_get_ln_fold(self.h, C.byref(on)), self.h)
         return bool(on.value)
 
+    def ln_guard(self):
+        """(max |row mean| / sigma seen since the weights were loaded, threshold, tripped) -- the fold's run-time guard."""
+        r, t, trip = C.c_float(0), C.c_float(0), C.c_int(0)
+        _check(lib().vh_get_ln_guard(self.h, C.byref(r), C.byref(t), C.byref(trip)), self.h)
+        return r.value, t.value, bool(trip.value)
+
     def load_weights(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         _check(lib().vh_load_weights(self.h, blob.ctypes.data, blob.nbytes), self.h)
@@ -418,6 +427,16 @@ class VitContext:
         avg, mn, n = C.c_double(0), C.c_double(0), C.c_int(0)
         _check(lib().vh_get_stage_timing(self.h, C.byref(avg), C.byref(mn), C.byref(n)), self.h)
         return avg.value, mn.value, n.value
+
+    def set_step_timing(self, on):
+        _check(lib().vh_set_step_timing(self.h, 1 if on else 0), self.h)
+
+    def get_step_timing(self, max_steps=4096):
+        """Device time in ms of every step of the last forward_device_async call (step timing enabled)."""
+        buf = (C.c_double * max_steps)()
+        n = C.c_int(0)
+        _check(lib().vh_get_step_timing(self.h, buf, max_steps, C.byref(n)), self.h)
+        return [buf[i] for i in range(min(n.value, max_steps))]
 
     def debug_read(self, what, n_floats):
         out = np.empty(n_floats, dtype=np.float32)
