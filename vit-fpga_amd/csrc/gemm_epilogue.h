@@ -408,92 +408,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
     }
 }
 
-// ---- register-path 16-bit epilogue (persistent GEMM, full tiles): no LDS round trip ---------------------------------
-// The staged form above pays, per pass, ds_write -> wait -> ds_read -> wait -> store on a 4 KiB slice that the next pass
-// must not overwrite before the reads are back: four dependent LDS round trips per tile with the matrix pipe idle.  Here
-// the transposition a full-width store needs is done between lanes instead.  Lane (fq, r) holds, for column block ni, the
-// 4 consecutive columns 4 fq .. 4 fq + 3 of row r (8 bytes packed).  For a PAIR of column blocks (a, b) one
-// v_permlane16_swap per packed dword (vdst = the block-a register, src = the block-b register: it exchanges the odd
-// 16-lane rows of vdst with the even rows of src) leaves
-//     even fq:  (vdst, src) = (own a, fq + 1's a)  = block a, columns 4 fq     .. 4 fq + 7
-//     odd  fq:  (vdst, src) = (fq - 1's b, own b)  = block b, columns 4 fq - 4 .. 4 fq + 3
-// i.e. 16 contiguous bytes per lane, and one store instruction writes 16 rows x 64 contiguous bytes (the two adjacent
-// blocks of the pair); the next pair completes each 128-byte line.  Same values, same bits as the staged form; the
-// arithmetic (epi_value16) is shared.
-#ifndef VH_EPI_DIRECT16
-#define VH_EPI_DIRECT16 0   // measured SLOWER than the staged form (16 B pieces per 16-lane group: see DESIGN.md); -DVH_EPI_DIRECT16=1 builds it
-#endif
-// `vec` (persistent GEMM): the tile's epilogue vectors, fetched into LDS by LDS-DMA while the main loop ran --
-// [256 x bias | 256 x c | 256 x (mean, rstd)] floats for the tile's 256 columns / rows (kEpiVecBytes); `col` / `row` =
-// the wave's first column / row inside the tile.  Read from there the epilogue issues NO global load: a load would
-// queue behind the next tile's prefetch DMAs in the in-order vmcnt (the staged form starts with exactly that wait).
-constexpr int kEpiVecBytes = 4096;
-template <typename T, int EPI, int MI, int NI>
-__device__ __forceinline__ void gemm_epilogue_direct16(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w, int lane,
-                                                       const char* vec = nullptr, int col = 0, int row = 0) {
-    static_assert(NI == 4 && epi_is_16bit(EPI), "64-column wave tile, 16-bit result");
-    using elem = typename T::elem;
-    const int N = e.N;
-    const int frow = lane & 15, fq = lane >> 4;
-    f32x4 bv[NI], cv[NI];
-    float2 lnst[epi_is_lnfold(EPI) ? MI : 1];
-    if (vec) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            bv[ni] = *(const f32x4*)(vec + (col + ni * 16 + fq * 4) * 4);
-            if constexpr (epi_is_lnfold(EPI)) cv[ni] = *(const f32x4*)(vec + 1024 + (col + ni * 16 + fq * 4) * 4);
-            else cv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if constexpr (epi_is_lnfold(EPI)) {
-            // The eight (mean, rstd) pairs of the lane's rows (128 B apart) by asm: written as ordinary loads hipcc merges them
-            // into ds_read2_b64, the merged instruction loses its alias information, and the wait-count pass answers an LDS
-            // read that "may alias" the K loop's LDS-DMA with s_waitcnt vmcnt(0) -- draining the next tile's prefetch.
-            static_assert(MI == 8, "eight row blocks per wave");
-            f32x4 p0, p1, p2, p3;
-            asm volatile("ds_read2_b64 %0, %4 offset1:16\n\tds_read2_b64 %1, %4 offset0:32 offset1:48\n\t"
-                         "ds_read2_b64 %2, %4 offset0:64 offset1:80\n\tds_read2_b64 %3, %4 offset0:96 offset1:112\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
-                         : "v"((uint32_t)(uintptr_t)vec + 2048 + (row + frow) * 8) : "memory");
-            lnst[0] = make_float2(p0[0], p0[1]); lnst[1] = make_float2(p0[2], p0[3]);
-            lnst[2] = make_float2(p1[0], p1[1]); lnst[3] = make_float2(p1[2], p1[3]);
-            lnst[4] = make_float2(p2[0], p2[1]); lnst[5] = make_float2(p2[2], p2[3]);
-            lnst[6] = make_float2(p3[0], p3[1]); lnst[7] = make_float2(p3[2], p3[3]);
-        }
-    } else {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
-            if constexpr (epi_is_lnfold(EPI)) cv[ni] = *(const f32x4*)(e.aux + n_w + ni * 16 + fq * 4);
-            else cv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if constexpr (epi_is_lnfold(EPI)) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)(m_w + mi * 16 + frow));
-        }
-    }
-    // the lane's 8 columns inside a pair of column blocks: block (fq & 1), columns (fq >> 1) * 8 ..
-    elem* const o = (elem*)e.out + (int64_t)(m_w + frow) * N + n_w + (fq & 1) * 16 + (fq >> 1) * 8;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        float rstd = 0.f, mr = 0.f;
-        if constexpr (epi_is_lnfold(EPI)) {
-            rstd = lnst[mi].y;
-            mr = lnst[mi].x * lnst[mi].y;
-        }
-#pragma unroll
-        for (int p = 0; p < NI / 2; ++p) {
-            const f32x4 va = epi_value16<EPI>(acc[mi][2 * p], bv[2 * p], cv[2 * p], mr, rstd);
-            const f32x4 vb = epi_value16<EPI>(acc[mi][2 * p + 1], bv[2 * p + 1], cv[2 * p + 1], mr, rstd);
-            const u32x2 a = __builtin_bit_cast(u32x2, pack4<T>(va[0], va[1], va[2], va[3]));
-            const u32x2 b = __builtin_bit_cast(u32x2, pack4<T>(vb[0], vb[1], vb[2], vb[3]));
-            const auto x = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-            const auto y = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-            epi_store(u32x4{x[0], y[0], x[1], y[1]}, (u32x4*)(o + (int64_t)mi * 16 * N + p * 32));
-        }
-    }
-}
-
 // Tiles whose 256/128 columns are all inside N take the staged path (rows are guarded inside); ragged-N tiles
 // and the patch-row remap store directly with per-element predicates.  `smem`: LDS holding NW * SMI * 2 KiB
 // from that address on.  With BARRIER it contains a workgroup barrier (needed when other waves may still be

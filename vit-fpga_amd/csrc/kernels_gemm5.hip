@@ -44,7 +44,6 @@
 //      L1: X fragments of row blocks 4-7                   C1: 16 MFMAs (row blocks 4-7)
 // (same 512 matrix cycles per phase, same 64 fragment registers).  W carries one fp32 scale per output channel
 // (`aux`), applied to the accumulators before the epilogue; activations are unscaled (vh_common.h, E4M3).
-#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -110,7 +109,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                   const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
                   void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn,
-                  const float* __restrict__ wscale, int stagger VH_STAMP_PARAM) {
+                  const float* __restrict__ wscale VH_STAMP_PARAM) {
     using vec8 = typename T::vec8;
 #ifdef VH_DIAG_STAMPS
     // the iteration whose stamps are kept: the workgroup's only tile, or the SECOND tile of a persistent workgroup
@@ -209,18 +208,6 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 
     const int nk = (int)(row_bytes / KT_BYTES);
 
-    // Persistent form: start-time stagger (launcher: gemm_stagger()).  `stagger` = groups | delay << 8: workgroup group
-    // g = (blockIdx.x / 8) % groups -- consecutive workgroups of one XCD fall into different groups -- sleeps g * delay
-    // units of ~1024 cycles before it touches memory.  All workgroups start together and a tile takes every CU the same
-    // time, so without it the whole chip reaches its epilogues at the same moment, writes one tile per CU (33.5 MB at
-    // 128 KiB each) into an HBM that takes 6.5 TB/s, and idles the write path for the rest of the tile period.
-    if constexpr (PERSIST) {
-        const int groups = stagger & 0xFF, delay = stagger >> 8;
-        if (groups > 1) {
-            const int n = ((blockIdx.x >> 3) % groups) * delay;
-            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-        }
-    }
     // ---- prologue of the first tile: K-tiles 0 and 1 ------------------------------------------------------------
     setup_tile(t);
     issue_w(0);
@@ -241,28 +228,10 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     // behind the two stages (160 KiB in this form), and its loads and stores simply join the in-order queue: its leading
     // loads wait for W(next, 1), issued one phase earlier; its stores are retired by the next tile's first counted wait.
     bool first = true;   // first tile of this workgroup: A(1) came from the prologue above
-    // Epilogue vectors through LDS (persistent form, register-path 16-bit epilogues): at the top of every tile waves 0-3
-    // fetch the tile's 256 bias values, 256 c values and 256 (mean, rstd) pairs by LDS-DMA into one of two 4 KiB buffers
-    // behind the stages (buffer = tile parity: the other one may still be read by a wave group finishing the previous
-    // tile).  These DMAs are the oldest entries of the tile's vmcnt queue, so the first counted wait of the K loop
-    // retires them and the barriers of the loop publish them; the epilogue then reads them with ds_read and contains
-    // no global load at all.
-    constexpr bool VEC_LDS = PERSIST && VH_EPI_DIRECT16 && epi_is_16bit(EPI) && !(F8 && epi_has_gelu(EPI));
-    int vbuf = 0;
     while (true) {
 #ifdef VH_DIAG_STAMPS
         if (first_tile_) VH_STAMP(0, diag_rt());
 #endif
-        if constexpr (VEC_LDS) {
-            // (asm form, vh_common.h: a DMA the compiler knows of would make it answer the epilogue's LDS reads with vmcnt(0))
-            const uint32_t vdst = (uint32_t)(uintptr_t)smem + 2 * STAGE_BYTES + vbuf * kEpiVecBytes;
-            if (wave == 0) asm_lds_dma16_keep_m0(bias + tile_n * BN, lane * 16, vdst);
-            if constexpr (epi_is_lnfold(EPI)) {
-                if (wave == 1) asm_lds_dma16_keep_m0(aux + tile_n * BN, lane * 16, vdst + 1024);
-                if (wave == 2) asm_lds_dma16_keep_m0(stats + 2 * (int64_t)tile_m * BM, lane * 16, vdst + 2048);
-                if (wave == 3) asm_lds_dma16_keep_m0(stats + 2 * ((int64_t)tile_m * BM + 128), lane * 16, vdst + 3072);
-            }
-        }
         f32x4 acc[MI][NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -441,8 +410,6 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                 gemm_epilogue8<EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, true, stage_epi, wave);
             else if constexpr (F8 && EPI == VH_EPI_RESID_LN)
                 gemm_epilogue_staged<E4M3, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
-            else if constexpr (VEC_LDS)   // 16-bit results: lane exchange instead of the LDS round trip, vectors from LDS
-                gemm_epilogue_direct16<T, EPI, MI, NI>(acc, e, m_w, n_w, lane_e, smem + 2 * STAGE_BYTES + vbuf * kEpiVecBytes, wn * 64, grp * 128);
             else
                 gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
         } else {
@@ -467,7 +434,6 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         ++it_;
 #endif
         if (!has_next) break;
-        vbuf ^= 1;
         par = (par + nk) & 1;
         first = false;
         t = t_next;
@@ -486,17 +452,6 @@ static int gemm_super_columns(int tiles_n) {
     if (tiles_n % 4 == 0) return 4;
     if (tiles_n % 3 == 0) return 3;
     return 4;
-}
-
-// start-time stagger of the persistent form: VH_PP_STAGGER="groups,delay" (delay in units of ~1024 shader cycles); 0 = off
-static int gemm_stagger() {
-    static const int v = [] {
-        const char* e = getenv("VH_PP_STAGGER");
-        int g = 0, d = 0;
-        if (e && sscanf(e, "%d,%d", &g, &d) == 2 && g > 1 && g < 256 && d > 0 && d < 4096) return g | (d << 8);
-        return 0;
-    }();
-    return v;
 }
 
 #ifdef VH_DIAG_STAMPS
@@ -527,7 +482,7 @@ static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int ti
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
                        tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n),
-                       F8 ? (g.wscale ? g.wscale : g.aux) : (const float*)nullptr, PERSIST ? gemm_stagger() : 0
+                       F8 ? (g.wscale ? g.wscale : g.aux) : (const float*)nullptr
                        VH_STAMP_ARG(g, EPI, F8, grid, PERSIST ? 6 : (AST == 3 ? 7 : 5)));
     return hipGetLastError();
 }

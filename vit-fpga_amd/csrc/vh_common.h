@@ -114,13 +114,6 @@ __device__ __forceinline__ void asm_lds_dma16(const void* base, uint32_t lane_of
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2"
                  :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory", "m0");
 }
-// The same for a kernel in which the COMPILER also issues LDS-DMA (__builtin_amdgcn_global_load_lds): M0 is
-// compiler-managed there and an "m0" clobber is not honoured, so the statement saves and restores it.
-__device__ __forceinline__ void asm_lds_dma16_keep_m0(const void* base, uint32_t lane_off, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(lane_off), "s"(base) : "memory");
-}
 // Returning atomic add on the wave-uniform address `base`, ISSUE only: `ret` is written when the operation completes,
 // i.e. the caller waits (vmcnt) before the first use of `ret` and keeps `ret`'s register untouched until then (the
 // attention work queue draws its ticket this way, one lane active).
