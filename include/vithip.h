@@ -367,6 +367,24 @@ int vh_mlp_load_params(vh_mlp* mlp, const float* params_host, size_t n_params,
 /* n_vec input vectors of n_ins floats -> n_vec output vectors of n_p_l[n_layers-1] floats */
 int vh_mlp_forward(vh_mlp* mlp, const float* inputs_host, int n_vec, float* outputs_host);
 int vh_mlp_last_forward_us(const vh_mlp* mlp, int64_t* us);
+/* Training of the dense chain: the device side of init_gradient / launch_gradient (netAbstract.h:14-15).  PARITY
+ * UNPINNED: the reference's bodies are commented-out code (netFPGA.cpp:518-580) on a vector library that is not in the
+ * repository.  Their loop shape is kept -- per iteration every set is back-propagated, its output error summed in
+ * absolute value, the sets' gradients accumulated, normalised, applied, the accumulator reset (:552-565) -- and what
+ * they leave undefined is fixed here:
+ *   loss of a set       1/2 |a_L - t|^2   (delta of the last layer = (a_L - t) * act'(z_L))
+ *   normalize_1         mean over the sets
+ *   update              p -= multiplier * mean gradient, all layers from the deltas of the SAME parameters
+ *   errors[it]          sum over sets and outputs of |a_L - t|, taken BEFORE the update of iteration `it`
+ *   error_threshold     an iteration with errors[it] <= error_threshold ends the loop; later entries stay 0 (the value
+ *                       the reference initialises its result with, :550)
+ *   act'                identity 1; RELU2 1 on (0, 1); RELU 1 on z > 0; HARDTANH 1 on (-1, 1); GELU Phi(z) + z phi(z)
+ * set_ins [n_sets][n_ins], set_outs [n_sets][n_p_l[n_layers-1]] (host); at most 65535 sets and neurons per layer.
+ * vh_mlp_read_params copies the (trained) parameters back in the layout vh_mlp_load_params takes. */
+int vh_mlp_init_gradient(vh_mlp* mlp, const float* set_ins_host, const float* set_outs_host, int n_sets);
+int vh_mlp_launch_gradient(vh_mlp* mlp, int iterations, float error_threshold, float multiplier, float* errors_host);
+int vh_mlp_read_params(vh_mlp* mlp, float* params_host, size_t n_params, float* bias_host, size_t n_neurons);
+int vh_mlp_last_gradient_us(const vh_mlp* mlp, int64_t* us);
 const char* vh_mlp_last_error(const vh_mlp* mlp);
 int vh_mlp_destroy(vh_mlp* mlp);
 

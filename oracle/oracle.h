@@ -107,6 +107,15 @@ int oracle_mlp_forward(int n_ins, int n_layers, const int* n_p_l, const float* p
 void oracle_mlp_random_params(float* params, size_t n_params, float* bias, size_t n_neurons,
                               uint32_t seed);
 
+/* Training of the dense chain (init_gradient / launch_gradient, netFPGA.cpp:518-580: commented-out code in the
+ * reference -- PARITY UNPINNED; the definitions are this build's, see mlp_oracle.c).  Full-batch gradient descent on
+ * 1/2 |a_L - t|^2: `params` / `bias` are updated in place, errors[it] = sum over sets and outputs of |a_L - t| BEFORE
+ * the update of iteration it; an iteration with error <= error_threshold ends the loop (later entries 0).
+ * set_ins [n_sets][n_ins], set_outs [n_sets][n_p_l[L-1]]. */
+int oracle_mlp_train(int n_ins, int n_layers, const int* n_p_l, float* params, float* bias, int activation,
+                     const float* set_ins, const float* set_outs, int n_sets, int iterations, float error_threshold,
+                     float multiplier, float* errors);
+
 #ifdef __cplusplus
 }
 #endif

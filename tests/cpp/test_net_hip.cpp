@@ -110,6 +110,35 @@ static void gpu_checks()
     for (int i = 0; i < 5; ++i) CHECK(std::fabs(y[i] - ref[i]) <= 1e-5f * (1.f + std::fabs(ref[i])));
     CHECK(net->get_forward_performance() > 0 && h->device_init);
 
+    // ---- MLP-mode training through the abstract interface vs the oracle's restatement (parity unpinned: f4) ------
+    {
+        const net::net_data td = make_net(12, {20, 9, 3});
+        std::unique_ptr<net::net_abstract> tn(new hip::net_hip(td, false, false));
+        hip::net_hip *th = static_cast<hip::net_hip *>(tn.get());
+        net::net_sets sets;
+        std::vector<float> fi, fo;
+        for (int j = 0; j < 6; ++j) {
+            std::vector<float> in(12), out(3);
+            for (int i = 0; i < 12; ++i) in[i] = std::sin(0.3f * i + j);
+            for (int i = 0; i < 3; ++i) out[i] = 0.5f + 0.4f * std::cos(1.1f * i + 0.7f * j);
+            fi.insert(fi.end(), in.begin(), in.end()); fo.insert(fo.end(), out.begin(), out.end());
+            sets.set_ins.push_back(in); sets.set_outs.push_back(out);
+        }
+        std::vector<float> rp(th->params, th->params + th->n_params), rb(th->bias, th->bias + th->n_neurons), rerr(15);
+        CHECK(tn->launch_gradient(4, -1.f, 0.1f) == std::vector<float>(4, 0.f));   // before init_gradient: the reference's zeros
+        tn->init_gradient(sets);
+        CHECK(th->gradient_init && th->n_sets == 6);
+        const std::vector<float> err = tn->launch_gradient(15, -1.f, 0.1f);
+        oracle_mlp_train(12, 3, th->n_p_l, rp.data(), rb.data(), th->activations, fi.data(), fo.data(), 6, 15, -1.f, 0.1f, rerr.data());
+        CHECK(err.size() == 15 && err[14] < err[0] && tn->get_gradient_performance() > 0);
+        for (int i = 0; i < 15; ++i) CHECK(std::fabs(err[i] - rerr[i]) <= 2e-4f * (1.f + rerr[i]));
+        float dmax = 0.f;
+        for (int i = 0; i < th->n_params; ++i) dmax = std::fmax(dmax, std::fabs(th->params[i] - rp[i]));
+        CHECK(dmax <= 2e-4f);                                    // the host copy follows the device: get_net_data() is the trained net
+        const net::net_data trained = tn->get_net_data();
+        CHECK(trained.params[0][0][0] == th->params[0] && trained.bias[2][2] == th->bias[th->n_neurons - 1]);
+    }
+
     // ---- ViT mode vs oracle ------------------------------------------------------------------
     oracle_vit_config oc = {64, 16, 3, 128, 2, 256, 2, 40, 1e-6f};
     vh_config c = {64, 16, 3, 128, 2, 256, 2, 40, VH_DTYPE_FP16, 1, 1e-6f, 0};

@@ -77,6 +77,9 @@ def lib():
         L.oracle_round_fp16.argtypes = [fp, C.c_int64]
         L.oracle_mlp_forward.restype = C.c_int
         L.oracle_mlp_forward.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), fp, fp, C.c_int, fp, fp]
+        L.oracle_mlp_train.restype = C.c_int
+        L.oracle_mlp_train.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), fp, fp, C.c_int, fp, fp, C.c_int, C.c_int,
+                                       C.c_float, C.c_float, fp]
         L.oracle_mlp_random_params.restype = None
         L.oracle_mlp_random_params.argtypes = [fp, C.c_size_t, fp, C.c_size_t, C.c_uint32]
         _lib = L
@@ -261,6 +264,20 @@ def mlp_forward(n_ins, n_p_l, params, bias, activation, inputs):
                                   _fp(_f32(inputs)), _fp(out))
     assert rc == 0
     return out
+
+
+def mlp_train(n_ins, n_p_l, params, bias, activation, set_ins, set_outs, iterations, threshold, multiplier):
+    """Full-batch gradient descent on the dense chain (oracle_mlp_train): returns (params, bias, errors)."""
+    npl = (C.c_int * len(n_p_l))(*n_p_l)
+    p, b = _f32(params).copy(), _f32(bias).copy()
+    si, so = _f32(set_ins), _f32(set_outs)
+    n_sets = si.size // n_ins
+    assert si.size == n_sets * n_ins and so.size == n_sets * n_p_l[-1]
+    err = np.zeros(max(iterations, 1), dtype=np.float32)
+    rc = lib().oracle_mlp_train(n_ins, len(n_p_l), npl, _fp(p), _fp(b), activation, _fp(si), _fp(so), n_sets, iterations,
+                                threshold, multiplier, _fp(err))
+    assert rc == 0
+    return p, b, err[:iterations]
 
 
 def mlp_random_params(n_params, n_neurons, seed):

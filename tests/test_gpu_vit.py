@@ -106,6 +106,29 @@ def test_layernorm_fold_is_a_property_of_the_configuration_not_of_the_workspace_
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp16"])
+def test_one_image_gives_the_same_bits_at_batch_1_128_300_and_512(dtype_name):
+    """The GEMM form depends on the row count -- 128x128 tiles at batch 1, one 256x256 tile per workgroup at 128, the
+    persistent form on rows padded to whole tiles at 300, on exact tiles at 512 -- and so does the attention grid.  Every
+    form adds a row's products in the same order, so image 0 must come out bit for bit the same from all of them (what
+    sharded == unsharded rests on)."""
+    cfg = S.CONFIGS["vit_base"]
+    dt = {"bf16": vithip.DTYPE_BF16, "fp16": vithip.DTYPE_FP16}[dtype_name]
+    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=512, flags=vithip.FLAG_LN_FOLD_ON)
+    ctx.init_weights_seeded(0)
+    px = cfg["image_size"] ** 2 * cfg["channels"]
+    din, dout = vithip.DeviceBuffer(512 * px * 4), vithip.DeviceBuffer(512 * cfg["classes"] * 4)
+    ctx.fill_input_seeded(1, 512, din.ptr)
+    rows = {}
+    for b in (1, 128, 300, 512):
+        ctx.forward_device(din.ptr, b, dout.ptr)
+        rows[b] = dout.to_numpy(np.float32, (b, cfg["classes"]))
+    ctx.close()
+    assert np.isfinite(rows[512]).all()
+    for b in (1, 128, 300):
+        assert np.array_equal(rows[b], rows[512][:b]), b
+
+
 def test_folded_layernorm_with_a_large_common_mode_row_mean():
     """The folded path multiplies the RAW rounded residual, so its operand rounding error is relative to |x| and not to
     |x - mean|: it grows like sqrt(1 + (mean/sigma)^2) with a common-mode offset of the rows.  Drive the residual stream

@@ -294,9 +294,10 @@ __device__ __forceinline__ float act_apply(int act, float v) {
     default: return v;
     }
 }
+// `z` (optional): the pre-activations, kept for the backward pass of MLP-mode training
 __global__ void __launch_bounds__(256)
 dense_layer_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ x,
-                   float* __restrict__ y, int n_in, int n_out, int n_vec, int act) {
+                   float* __restrict__ y, int n_in, int n_out, int n_vec, int act, float* __restrict__ z) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_out) return;
@@ -307,13 +308,91 @@ dense_layer_kernel(const float* __restrict__ w, const float* __restrict__ b, con
         for (int k = lane; k < n_in; k += 64) s = fmaf(wr[k], xv[k], s);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) y[(int64_t)v * n_out + j] = act_apply(act, s + b[j]);
+        if (lane == 0) {
+            const float pre = s + b[j];
+            if (z) z[(int64_t)v * n_out + j] = pre;
+            y[(int64_t)v * n_out + j] = act_apply(act, pre);
+        }
     }
 }
 hipError_t launch_dense_layer(const float* w, const float* b, const float* x, float* y, int n_in, int n_out, int n_vec,
-                              int activation, hipStream_t s) {
+                              int activation, hipStream_t s, float* z) {
     hipLaunchKernelGGL(dense_layer_kernel, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, s, w, b, x, y, n_in, n_out,
-                       n_vec, activation);
+                       n_vec, activation, z);
+    return hipGetLastError();
+}
+
+// ---- MLP-mode training (init_gradient / launch_gradient, netFPGA.cpp:518-580: commented-out code in the reference; the
+// definitions are this build's -- include/vithip.h, oracle/mlp_oracle.c).  Small fp32 kernels, every sum in a fixed order.
+__device__ __forceinline__ float act_deriv(int act, float z) {
+    switch (act) {
+    case VH_ACT_RELU2: return (z > 0.f && z < 1.f) ? 1.f : 0.f;
+    case VH_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case VH_ACT_HARDTANH: return (z > -1.f && z < 1.f) ? 1.f : 0.f;
+    case VH_ACT_GELU: return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * expf(-0.5f * z * z);
+    default: return 1.f;
+    }
+}
+// last layer: d = (a - t) * act'(z); err = sum |a - t| over all sets and outputs.  ONE workgroup: every thread adds its
+// elements in index order, then a fixed tree -- the same bits on every run.
+__global__ void __launch_bounds__(1024)
+mlp_out_delta_kernel(const float* __restrict__ a, const float* __restrict__ z, const float* __restrict__ t, float* __restrict__ d,
+                     int64_t n, int act, float* __restrict__ err) {
+    __shared__ float part[1024];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float e = a[i] - t[i];
+        s += fabsf(e);
+        d[i] = e * act_deriv(act, z[i]);
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *err = part[0];
+}
+// hidden layer: d_prev[j][i] = act'(z_prev[j][i]) * sum_o W[o][i] d[j][o]   (W of the layer ABOVE, before its update)
+__global__ void __launch_bounds__(256)
+mlp_back_delta_kernel(const float* __restrict__ w, const float* __restrict__ d, const float* __restrict__ z_prev,
+                      float* __restrict__ d_prev, int n_in, int n_out, int act) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= n_in) return;
+    const float* dj = d + (int64_t)j * n_out;
+    float s = 0.f;
+    for (int o = 0; o < n_out; ++o) s = fmaf(w[(int64_t)o * n_in + i], dj[o], s);
+    d_prev[(int64_t)j * n_in + i] = s * act_deriv(act, z_prev[(int64_t)j * n_in + i]);
+}
+// W[o][k] -= scale * sum_j d[j][o] x[j][k];  b[o] -= scale * sum_j d[j][o]     (scale = multiplier / n_sets)
+__global__ void __launch_bounds__(256)
+mlp_update_kernel(float* __restrict__ w, float* __restrict__ b, const float* __restrict__ d, const float* __restrict__ x,
+                  int n_in, int n_out, int n_sets, float scale) {
+    const int k = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
+    if (k < n_in) {
+        float g = 0.f;
+        for (int j = 0; j < n_sets; ++j) g = fmaf(d[(int64_t)j * n_out + o], x[(int64_t)j * n_in + k], g);
+        w[(int64_t)o * n_in + k] -= scale * g;
+    }
+    if (k == 0) {
+        float gb = 0.f;
+        for (int j = 0; j < n_sets; ++j) gb += d[(int64_t)j * n_out + o];
+        b[o] -= scale * gb;
+    }
+}
+hipError_t launch_mlp_out_delta(const float* a, const float* z, const float* t, float* d, int64_t n, int act, float* err, hipStream_t s) {
+    hipLaunchKernelGGL(mlp_out_delta_kernel, dim3(1), dim3(1024), 0, s, a, z, t, d, n, act, err);
+    return hipGetLastError();
+}
+hipError_t launch_mlp_back_delta(const float* w, const float* d, const float* z_prev, float* d_prev, int n_in, int n_out, int n_sets,
+                                 int act, hipStream_t s) {
+    hipLaunchKernelGGL(mlp_back_delta_kernel, dim3((unsigned)((n_in + 255) / 256), (unsigned)n_sets), dim3(256), 0, s, w, d, z_prev, d_prev,
+                       n_in, n_out, act);
+    return hipGetLastError();
+}
+hipError_t launch_mlp_update(float* w, float* b, const float* d, const float* x, int n_in, int n_out, int n_sets, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(mlp_update_kernel, dim3((unsigned)((n_in + 255) / 256), (unsigned)n_out), dim3(256), 0, s, w, b, d, x, n_in, n_out,
+                       n_sets, scale);
     return hipGetLastError();
 }
 

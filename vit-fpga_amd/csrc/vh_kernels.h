@@ -94,7 +94,14 @@ hipError_t launch_fold_ln(const float* w, const float* b, const float* gamma, co
                           float scale, void* w16, float* c, float* d, int dtype, hipStream_t stream);
 // MLP mode: y = act(W x + b), W [n_out, n_in] fp32
 hipError_t launch_dense_layer(const float* w, const float* b, const float* x, float* y, int n_in,
-                              int n_out, int n_vec, int activation, hipStream_t stream);
+                              int n_out, int n_vec, int activation, hipStream_t stream, float* z = nullptr);
+// MLP-mode training (kernels_misc.hip): last-layer delta + error, hidden-layer delta, parameter update
+hipError_t launch_mlp_out_delta(const float* a, const float* z, const float* t, float* d, int64_t n, int act, float* err,
+                                hipStream_t stream);
+hipError_t launch_mlp_back_delta(const float* w, const float* d, const float* z_prev, float* d_prev, int n_in, int n_out,
+                                 int n_sets, int act, hipStream_t stream);
+hipError_t launch_mlp_update(float* w, float* b, const float* d, const float* x, int n_in, int n_out, int n_sets, float scale,
+                             hipStream_t stream);
 
 // 3x3 filter on 8-bit frames (filter_image): kind 0 = binomial blur, 1 = Sobel |gx|+|gy|
 hipError_t launch_filter3x3(const uint8_t* in, uint8_t* out, int h, int w, int kind, hipStream_t stream);

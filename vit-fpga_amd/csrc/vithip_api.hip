@@ -256,6 +256,11 @@ struct vh_mlp {
     float *params = nullptr, *bias = nullptr, *buf0 = nullptr, *buf1 = nullptr;
     bool loaded = false;
     int64_t last_us = 0;
+    // training (vh_mlp_init_gradient / vh_mlp_launch_gradient): the sets and, per set and neuron, pre-activation,
+    // activation and delta
+    int n_sets = 0;
+    float *set_ins = nullptr, *set_outs = nullptr, *tz = nullptr, *ta = nullptr, *td = nullptr, *terr = nullptr;
+    int64_t last_gradient_us = 0;
     std::string err;
 };
 
@@ -1824,6 +1829,84 @@ int vh_mlp_forward(vh_mlp* m, const float* in, int n_vec, float* outp) {
     return VH_OK;
 }
 
+// ---- MLP-mode training (netFPGA.cpp:518-580 is commented-out code: the definitions are in include/vithip.h)
+int vh_mlp_init_gradient(vh_mlp* m, const float* set_ins, const float* set_outs, int n_sets) {
+    if (!m || !set_ins || !set_outs || n_sets <= 0) return fail(m ? &m->err : nullptr, VH_ERR_INVALID, "vh_mlp_init_gradient: bad argument");
+    if (!m->loaded) return fail(&m->err, VH_ERR_STATE, "init_gradient before params were loaded");
+    if (n_sets > 65535) return fail(&m->err, VH_ERR_INVALID, "at most 65535 sets");
+    for (int n : m->npl) if (n > 65535) return fail(&m->err, VH_ERR_INVALID, "training supports layers of at most 65535 neurons");
+    HIPCHK(&m->err, hipSetDevice(m->device));
+    for (float** p : {&m->set_ins, &m->set_outs, &m->tz, &m->ta, &m->td, &m->terr}) { if (*p) hipFree(*p); *p = nullptr; }
+    m->n_sets = 0;
+    const size_t n_out = (size_t)m->npl.back();
+    HIPCHK(&m->err, hipMalloc((void**)&m->set_ins, (size_t)n_sets * m->n_ins * 4));
+    HIPCHK(&m->err, hipMalloc((void**)&m->set_outs, (size_t)n_sets * n_out * 4));
+    HIPCHK(&m->err, hipMalloc((void**)&m->tz, m->n_neurons * n_sets * 4));
+    HIPCHK(&m->err, hipMalloc((void**)&m->ta, m->n_neurons * n_sets * 4));
+    HIPCHK(&m->err, hipMalloc((void**)&m->td, m->n_neurons * n_sets * 4));
+    HIPCHK(&m->err, hipMalloc((void**)&m->terr, 4));
+    HIPCHK(&m->err, hipMemcpyAsync(m->set_ins, set_ins, (size_t)n_sets * m->n_ins * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(&m->err, hipMemcpyAsync(m->set_outs, set_outs, (size_t)n_sets * n_out * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(&m->err, hipStreamSynchronize(m->stream));
+    m->n_sets = n_sets;
+    return VH_OK;
+}
+
+int vh_mlp_launch_gradient(vh_mlp* m, int iterations, float error_threshold, float multiplier, float* errors) {
+    if (!m || iterations < 0 || (iterations > 0 && !errors)) return fail(m ? &m->err : nullptr, VH_ERR_INVALID, "vh_mlp_launch_gradient: bad argument");
+    if (m->n_sets <= 0) return fail(&m->err, VH_ERR_STATE, "launch_gradient before init_gradient");
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    HIPCHK(&m->err, hipSetDevice(m->device));
+    const int S = m->n_sets, L = m->n_layers;
+    const float scale = multiplier / (float)S;
+    // layer l's slices of the per-set buffers start at noff[l] * S floats
+    std::vector<size_t> woff(L), noff(L);
+    { size_t w = 0, n = 0; int fan = m->n_ins; for (int l = 0; l < L; ++l) { woff[l] = w; noff[l] = n; w += (size_t)m->npl[l] * fan; n += (size_t)m->npl[l]; fan = m->npl[l]; } }
+    auto fan_in = [&](int l) { return l == 0 ? m->n_ins : m->npl[l - 1]; };
+    auto act_in = [&](int l) -> const float* { return l == 0 ? m->set_ins : m->ta + noff[l - 1] * S; };
+    for (int it = 0; it < iterations; ++it) errors[it] = 0.f;
+    for (int it = 0; it < iterations; ++it) {
+        for (int l = 0; l < L; ++l)
+            HIPCHK(&m->err, launch_dense_layer(m->params + woff[l], m->bias + noff[l], act_in(l), m->ta + noff[l] * S, fan_in(l), m->npl[l], S,
+                                               m->activation, m->stream, m->tz + noff[l] * S));
+        const int n_out = m->npl[L - 1];
+        HIPCHK(&m->err, launch_mlp_out_delta(m->ta + noff[L - 1] * S, m->tz + noff[L - 1] * S, m->set_outs, m->td + noff[L - 1] * S,
+                                             (int64_t)S * n_out, m->activation, m->terr, m->stream));
+        // the error decides whether this iteration updates: one 4-byte read back per iteration (the reference's loop is
+        // host-driven as well, netFPGA.cpp:552-565)
+        HIPCHK(&m->err, hipMemcpyAsync(&errors[it], m->terr, 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(&m->err, hipStreamSynchronize(m->stream));
+        if (errors[it] <= error_threshold) break;
+        for (int l = L - 1; l >= 1; --l)   // deltas back to front, all with the parameters of THIS iteration
+            HIPCHK(&m->err, launch_mlp_back_delta(m->params + woff[l], m->td + noff[l] * S, m->tz + noff[l - 1] * S, m->td + noff[l - 1] * S,
+                                                  m->npl[l - 1], m->npl[l], S, m->activation, m->stream));
+        for (int l = 0; l < L; ++l)
+            HIPCHK(&m->err, launch_mlp_update(m->params + woff[l], m->bias + noff[l], m->td + noff[l] * S, act_in(l), fan_in(l), m->npl[l], S,
+                                              scale, m->stream));
+    }
+    HIPCHK(&m->err, hipStreamSynchronize(m->stream));
+    m->last_gradient_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+    return VH_OK;
+}
+
+int vh_mlp_read_params(vh_mlp* m, float* params, size_t n_params, float* bias, size_t n_neurons) {
+    if (!m || !params || !bias) return fail(m ? &m->err : nullptr, VH_ERR_INVALID, "null argument");
+    if (n_params != m->n_params || n_neurons != m->n_neurons)
+        return fail(&m->err, VH_ERR_INVALID, "expected %zu params / %zu neurons, got %zu / %zu", m->n_params, m->n_neurons, n_params, n_neurons);
+    if (!m->loaded) return fail(&m->err, VH_ERR_STATE, "no params loaded");
+    HIPCHK(&m->err, hipSetDevice(m->device));
+    HIPCHK(&m->err, hipMemcpyAsync(params, m->params, n_params * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(&m->err, hipMemcpyAsync(bias, m->bias, n_neurons * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(&m->err, hipStreamSynchronize(m->stream));
+    return VH_OK;
+}
+
+int vh_mlp_last_gradient_us(const vh_mlp* m, int64_t* us) {
+    if (!m || !us) return fail(nullptr, VH_ERR_INVALID, "null argument");
+    *us = m->last_gradient_us;
+    return VH_OK;
+}
+
 int vh_mlp_last_forward_us(const vh_mlp* m, int64_t* us) {
     if (!m || !us) return fail(nullptr, VH_ERR_INVALID, "null argument");
     *us = m->last_us;
@@ -1839,6 +1922,7 @@ int vh_mlp_destroy(vh_mlp* m) {
     if (m->bias) hipFree(m->bias);
     if (m->buf0) hipFree(m->buf0);
     if (m->buf1) hipFree(m->buf1);
+    for (float* p : {m->set_ins, m->set_outs, m->tz, m->ta, m->td, m->terr}) if (p) hipFree(p);
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
     return VH_OK;

@@ -462,14 +462,56 @@ namespace hip
         return 0.0;
     }
 
-    // ---- training: stubs with the reference's observable behaviour (bodies commented out there) ----
-    void net_hip::init_gradient(const net::net_sets &sets) { (void)sets; } // netFPGA.cpp:518-542
+    // ---- training ----
+    // The reference's bodies are commented-out code (netFPGA.cpp:518-580); their observable behaviour -- init_gradient
+    // does nothing, launch_gradient returns `iterations` zeros -- is kept wherever this build has nothing better: in ViT
+    // mode, and in MLP mode before init_gradient.  In MLP mode the loop the comments sketch is implemented on the
+    // device (vh_mlp_init_gradient / vh_mlp_launch_gradient; the definitions the reference leaves open are stated in
+    // include/vithip.h and restated on the CPU in oracle/mlp_oracle.c -- PARITY UNPINNED).
+    void net_hip::init_gradient(const net::net_sets &sets)
+    {
+        if (vit_mode || gradient_init) // a second call is ignored, as in the reference's sketch (:520, :541)
+            return;
+        const size_t n = sets.set_ins.size();
+        if (n == 0 && sets.set_outs.empty())
+            return; // nothing to train on: launch_gradient keeps returning zeros (no device is touched)
+        if (sets.set_outs.size() != n)
+            die("init_gradient", "set_ins and set_outs must hold the same number of sets");
+        const size_t n_out = (size_t)n_p_l[n_layers - 1];
+        vector<DATA_TYPE> ins, outs;
+        ins.reserve(n * (size_t)n_ins);
+        outs.reserve(n * n_out);
+        for (size_t j = 0; j < n; j++)
+        {
+            if (sets.set_ins[j].size() != (size_t)n_ins || sets.set_outs[j].size() != n_out)
+                die("init_gradient", "every set needs n_ins inputs and n_p_l[n_layers-1] outputs");
+            ins.insert(ins.end(), sets.set_ins[j].begin(), sets.set_ins[j].end());
+            outs.insert(outs.end(), sets.set_outs[j].begin(), sets.set_outs[j].end());
+        }
+        ensure_device(1);
+        if (vh_mlp_init_gradient(mlp, ins.data(), outs.data(), (int)n) != VH_OK)
+            die("vh_mlp_init_gradient", vh_mlp_last_error(mlp));
+        n_sets = (int)n;
+        gradient_init = true;
+    }
 
     vector<DATA_TYPE> net_hip::launch_gradient(size_t iterations, DATA_TYPE error_threshold, DATA_TYPE multiplier)
     {
-        (void)error_threshold;
-        (void)multiplier;
-        return vector<DATA_TYPE>(iterations, 0); // netFPGA.cpp:579
+        vector<DATA_TYPE> errors(iterations, 0); // netFPGA.cpp:550, :579
+        if (vit_mode || !gradient_init || iterations == 0)
+            return errors;
+#ifdef PERFORMANCE
+        const auto start = chrono::high_resolution_clock::now(); // the window the reference sketches, :546-547, :566-568
+#endif
+        if (vh_mlp_launch_gradient(mlp, (int)iterations, error_threshold, multiplier, errors.data()) != VH_OK)
+            die("vh_mlp_launch_gradient", vh_mlp_last_error(mlp));
+        // the host copy follows the device, so that get_net_data() returns the trained net
+        if (vh_mlp_read_params(mlp, params, (size_t)n_params, bias, (size_t)n_neurons) != VH_OK)
+            die("vh_mlp_read_params", vh_mlp_last_error(mlp));
+#ifdef PERFORMANCE
+        gradient_performance = chrono::duration_cast<chrono::microseconds>(chrono::high_resolution_clock::now() - start).count();
+#endif
+        return errors;
     }
 
     void net_hip::print_inner_vals() {} // netFPGA.cpp:582-591

@@ -126,6 +126,10 @@ SYMBOLS = {
     "vh_mlp_load_params": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vh_mlp_forward": (_i, [_vp, _vp, _i, _vp]),
     "vh_mlp_last_forward_us": (_i, [_vp, C.POINTER(_i64)]),
+    "vh_mlp_init_gradient": (_i, [_vp, _vp, _vp, _i]),
+    "vh_mlp_launch_gradient": (_i, [_vp, _i, _f, _f, _vp]),
+    "vh_mlp_read_params": (_i, [_vp, _vp, _sz, _vp, _sz]),
+    "vh_mlp_last_gradient_us": (_i, [_vp, C.POINTER(_i64)]),
     "vh_mlp_last_error": (C.c_char_p, [_vp]),
     "vh_mlp_destroy": (_i, [_vp]),
 }
@@ -536,6 +540,30 @@ class MlpContext:
         out = np.empty((x.shape[0], self.n_p_l[-1]), dtype=np.float32)
         self._chk(lib().vh_mlp_forward(self.h, x.ctypes.data, x.shape[0], out.ctypes.data))
         return out
+
+    def init_gradient(self, set_ins, set_outs):
+        si = np.ascontiguousarray(set_ins, dtype=np.float32).reshape(-1, self.n_ins)
+        so = np.ascontiguousarray(set_outs, dtype=np.float32).reshape(si.shape[0], self.n_p_l[-1])
+        self._chk(lib().vh_mlp_init_gradient(self.h, si.ctypes.data, so.ctypes.data, si.shape[0]))
+
+    def launch_gradient(self, iterations, error_threshold, multiplier):
+        err = np.zeros(max(iterations, 1), dtype=np.float32)
+        self._chk(lib().vh_mlp_launch_gradient(self.h, iterations, error_threshold, multiplier, err.ctypes.data))
+        return err[:iterations]
+
+    def read_params(self):
+        fan, n_params = self.n_ins, 0
+        for n in self.n_p_l:
+            n_params += n * fan
+            fan = n
+        p, b = np.empty(n_params, dtype=np.float32), np.empty(sum(self.n_p_l), dtype=np.float32)
+        self._chk(lib().vh_mlp_read_params(self.h, p.ctypes.data, p.size, b.ctypes.data, b.size))
+        return p, b
+
+    def last_gradient_us(self):
+        us = C.c_int64(0)
+        self._chk(lib().vh_mlp_last_gradient_us(self.h, C.byref(us)))
+        return us.value
 
     def close(self):
         if self.h:
