@@ -11,10 +11,12 @@ ref = O.vit_forward(cfg, blob, images)
 fold = os.environ.get("PARITY_FOLD", "default")
 flags = {"on": vithip.FLAG_LN_FOLD_ON, "off": vithip.FLAG_LN_FOLD_OFF}.get(fold, 0)
 for name, dt in (("fp16", vithip.DTYPE_FP16), ("bf16", vithip.DTYPE_BF16), ("fp8", vithip.DTYPE_FP8)):
-    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=n, flags=flags); ctx.load_weights(blob); got = ctx.forward(images); ctx.close()
+    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=n, flags=flags); ctx.load_weights(blob); got = ctx.forward(images)
+    guard = ctx.ln_guard(); ctx.close()
     per = np.abs(got - ref).max(1) / np.abs(ref).max()
     rms = np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2))
     top1 = (got.argmax(1) == ref.argmax(1)).mean()
     top5 = np.mean([len(set(np.argsort(-got[i])[:5]) & set(np.argsort(-ref[i])[:5])) / 5 for i in range(n)])
     print(f"vit_base {n} images {name} LayerNorm fold={fold}: max|d|/max|ref| worst {per.max():.3e} median {np.median(per):.3e}; "
-          f"rms {rms:.3e}; top-1 agreement {top1:.3f}, top-5 overlap {top5:.3f}")
+          f"rms {rms:.3e}; top-1 agreement {top1:.3f}, top-5 overlap {top5:.3f}; fold guard: max |row mean|/sigma {guard[0]:.3f} "
+          f"(threshold {guard[1]:.2f}, tripped {guard[2]})")

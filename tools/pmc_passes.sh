@@ -12,7 +12,7 @@ run() {  # name, counters...
   local name=$1; shift
   rm -rf $out/pmc_${tag}_$name
   timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/pmc_${tag}_$name -- \
-      python3 bench.py --no-cpu-baseline --no-parity --no-fp16-line --steps 3 --warmup 1 "${EXTRA[@]}" > $out/pmc_${tag}_$name.log 2>&1
+      python3 bench.py --no-cpu-baseline --no-parity --no-fp16-line --no-extra-configs --steps 3 --warmup 1 "${EXTRA[@]}" > $out/pmc_${tag}_$name.log 2>&1
 }
 EXTRA=("$@")
 run mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
