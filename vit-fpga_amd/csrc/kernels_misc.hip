@@ -510,12 +510,14 @@ hipError_t launch_layernorm_split(const void* hi, const void* lo, int64_t rows, 
 // UNCENTRED rows, so its rounding error relative to the centred signal grows with sqrt(1 + (mean/sigma)^2); every row of
 // the first `guard_rows` rows (the real ones: rows behind them are tile padding) contributes |mean| * rstd to a running
 // maximum kept as the bits of a non-negative float (ordered like unsigned integers; a NaN ranks above everything and
-// trips the guard too).  One atomic per wave.
+// trips the guard too).  A wave first READS the word (an L2 hit shared by everybody) and issues its atomic only when it
+// would raise it: after the first forward the maximum stands and no atomic is issued at all (one atomic per wave
+// unconditionally -- 1 576 on one address per launch -- tripled the kernel's time).
 __device__ __forceinline__ void ln_guard_update(float ratio, unsigned int* guard) {
     unsigned int b = __float_as_uint(ratio) & 0x7FFFFFFFu;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)b, o); b = t > b ? t : b; }
-    if ((threadIdx.x & 63) == 0 && b) atomicMax(guard, b);
+    if ((threadIdx.x & 63) == 0 && b > __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(guard, b);
 }
 __global__ void __launch_bounds__(256)
 finalize_stats_kernel(const float* __restrict__ partials, int nblk, int64_t rows, int dim, float eps, float* __restrict__ stats,
