@@ -24,7 +24,7 @@ def main():
     L.vh_diag_stamps_arm.argtypes = [ctypes.c_int, ctypes.c_int]
     L.vh_diag_stamps_read.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     max_wgs = 8192
-    buf = np.zeros((max_wgs, 8, 8), dtype=np.uint64)
+    buf = np.zeros((max_wgs, 8, 16), dtype=np.uint64)
     meta = (ctypes.c_longlong * 8)()
     print(f"{'epilogue':12s} {'N':>5s} {'K':>5s} {'tiles':>6s} | main us | epilogue issue us: G0   G1 | + drain us: G0   G1 | tile us (G1 end)")
     for epi, N, K in ((vithip.EPI_BIAS, 2304, 768), (vithip.EPI_LNFOLD, 2304, 768), (vithip.EPI_LNFOLD_GELU, 3072, 768),

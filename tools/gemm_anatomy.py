@@ -68,7 +68,7 @@ def main():
 
     groups = {}
     n = min(args.launches, int(L.vh_diag_stamps_count()))
-    buf = np.zeros((max_wgs, 8, 8), dtype=np.uint64)   # [workgroup][wave][stamp]
+    buf = np.zeros((max_wgs, 8, 16), dtype=np.uint64)   # [workgroup][wave][stamp]: 0-7 tile stamps, 8-15 phase stamps of one K-tile
     meta = (ctypes.c_longlong * 8)()
     for age in range(n):
         if L.vh_diag_stamps_read(age, buf.ctypes.data, max_wgs, meta):
@@ -151,6 +151,21 @@ def main():
         if sp:
             a = np.mean(np.array(sp), axis=0)
             print(f"      epilogue start across the workgroups of a launch, us around the median: p5 {a[0]:+.2f}  p25 {a[1]:+.2f}  p75 {a[2]:+.2f}  p95 {a[3]:+.2f}  (sigma {a[4]:.2f})")
+        # one K-tile (the middle one of the stamped tile) phase by phase, shader cycles, median over workgroups and launches:
+        # work = until the phase's last instruction has issued (L phases: reads back + DMA issued + counted wait), wait = at
+        # the barrier that closes it.  G0 = wave 0, G1 = wave 4 (one barrier behind).
+        if not f8:
+            rows = []
+            for w_ in (0, 4):
+                ph = np.concatenate([st8[:, w_, 8:16].astype(np.int64) for st8 in launches])
+                ph = ph[(ph[:, 0] > 0) & (ph[:, 7] > ph[:, 0])]
+                if len(ph):
+                    d = np.diff(ph, axis=1)
+                    rows.append((w_, np.median(d, axis=0), np.median(ph[:, 7] - ph[:, 0])))
+            if rows:
+                print("      one K-tile, shader cycles (median): L0 work | L0 barrier | C0 issue | C0 barrier | L1 work+wait | L1 barrier | C1 issue+wait |  sum of these 7")
+                for w_, d, tot in rows:
+                    print(f"        wave {w_} (G{w_ // 4}): " + " ".join(f"{x:12.0f}" for x in d) + f" | {tot:8.0f}   (K-tile at this clock: {m_us * c * 1e3 / nk:6.0f} cycles, MFMA 2048 per SIMD)")
         if nwv:
             wv /= nwv
             print("      per wave (us after wave 0's top-of-tile stamp): loop entered | main loop done | epilogue issued | iteration end")

@@ -84,7 +84,15 @@ __device__ __forceinline__ unsigned long long diag_hwid() {
     return ((unsigned long long)xcc << 32) | hw;
 }
 #define VH_STAMP(i, expr) do { __builtin_amdgcn_sched_barrier(0); st_[i] = (expr); __builtin_amdgcn_sched_barrier(0); } while (0)
+// Phase stamps of ONE K-tile (the middle one) of the stamped tile, written straight to the stamp record's words 8-15 by
+// lane 0 (nothing is kept in registers across the K loop): shader clock at  0 top of L0 | 1 L0's reads back, DMA issued |
+// 2 past L0's barrier | 3 C0's MFMAs issued | 4 past C0's barrier | 5 L1's reads back, DMA issued, counted wait passed |
+// 6 past L1's barrier | 7 C1's MFMAs issued and its counted wait passed.  (The stores are vector-memory operations of
+// their own: they make the K-tile's counted waits stricter, never laxer.)
+#define VH_PSTAMP(i) do { if (pst_) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = diag_ct(); \
+    if (lane == 0) pst_[i] = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
+#define VH_PSTAMP(i) do { } while (0)
 #define VH_STAMP_PARAM
 #define VH_STAMP(i, expr) do { } while (0)
 #endif
@@ -331,6 +339,10 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         for (int kt = 0, k3 = 0; kt < nk; ++kt, k3 = k3 == 2 ? 0 : k3 + 1) {
             const char* sa = smem + a_off(kt, k3) + xbase;
             const char* sw = smem + w_off(kt) + wbase;
+#ifdef VH_DIAG_STAMPS
+            unsigned long long* const pst_ = (first_tile_ && stamps && kt == nk / 2) ? stamps + ((size_t)blockIdx.x * 8 + wave) * 16 + 8 : nullptr;
+#endif
+            VH_PSTAMP(0);
             // ---- L0 ------------------------------------------------------------------------------------------------
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
@@ -341,7 +353,9 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(sa + mi * 2048 + off0);
             l0_issue(kt, k3);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            VH_PSTAMP(1);
             pp_barrier();
+            VH_PSTAMP(2);
             // ---- C0 ------------------------------------------------------------------------------------------------
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -349,13 +363,17 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf0[ni], xf[mi], acc[mi][ni]);
             __builtin_amdgcn_s_setprio(0);
+            VH_PSTAMP(3);
             pp_barrier();
+            VH_PSTAMP(4);
             // ---- L1 ------------------------------------------------------------------------------------------------
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(sa + mi * 2048 + off1);
             l1_issue_wait(kt);
             __builtin_amdgcn_s_waitcnt(0xC07F);
+            VH_PSTAMP(5);
             pp_barrier();
+            VH_PSTAMP(6);
             // ---- C1 ------------------------------------------------------------------------------------------------
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -364,6 +382,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf1[ni], xf[mi], acc[mi][ni]);
             __builtin_amdgcn_s_setprio(0);
             c1_wait(kt);
+            VH_PSTAMP(7);
             pp_barrier();
         }
         }
@@ -428,7 +447,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             st_[7] = diag_hwid();
             if (stamps && lane == 0) {   // one record per wave
 #pragma unroll
-                for (int i = 0; i < 8; ++i) stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = st_[i];
+                for (int i = 0; i < 8; ++i) stamps[((size_t)blockIdx.x * 8 + wave) * 16 + i] = st_[i];
             }
         }
         ++it_;
@@ -466,7 +485,7 @@ static unsigned long long* diag_next(const GemmArgs& g, int epi, bool f8, int gr
     const int slot = (int)(g_diag_count % g_diag_slots);
     g_diag_rec[slot] = DiagRec{g.M, g.N, g.K, epi, f8 ? 1 : 0, grid, variant};
     ++g_diag_count;
-    return g_diag_buf + (size_t)slot * g_diag_max_wgs * 64;
+    return g_diag_buf + (size_t)slot * g_diag_max_wgs * 128;
 }
 #define VH_STAMP_ARG(g, epi, f8, grid, variant) , diag_next(g, epi, f8, grid, variant)
 #else
@@ -567,12 +586,12 @@ extern "C" int vh_diag_stamps_arm(int slots, int max_wgs) {
     using namespace vh;
     if (slots < 1 || slots > 1024 || max_wgs < 1) return 1;
     if (g_diag_buf) { hipFree(g_diag_buf); g_diag_buf = nullptr; }
-    if (hipMalloc((void**)&g_diag_buf, (size_t)slots * max_wgs * 512) != hipSuccess) return 2;
-    if (hipMemset(g_diag_buf, 0, (size_t)slots * max_wgs * 512) != hipSuccess) return 2;
+    if (hipMalloc((void**)&g_diag_buf, (size_t)slots * max_wgs * 1024) != hipSuccess) return 2;
+    if (hipMemset(g_diag_buf, 0, (size_t)slots * max_wgs * 1024) != hipSuccess) return 2;
     g_diag_slots = slots; g_diag_max_wgs = max_wgs; g_diag_count = 0;
     return 0;
 }
-// age 0 = the most recent launch; copies grid x 8 waves x 8 words; meta = {M, N, K, epi, f8, grid, variant}
+// age 0 = the most recent launch; copies grid x 8 waves x 16 words (0-7 tile stamps, 8-15 phase stamps of one K-tile); meta = {M, N, K, epi, f8, grid, variant}
 extern "C" int vh_diag_stamps_read(int age, unsigned long long* host, int max_wgs, long long* meta) {
     using namespace vh;
     if (!g_diag_buf || age < 0 || age >= g_diag_slots || age >= g_diag_count) return 1;
@@ -580,7 +599,7 @@ extern "C" int vh_diag_stamps_read(int age, unsigned long long* host, int max_wg
     const int slot = (int)((g_diag_count - 1 - age) % g_diag_slots);
     const DiagRec& r = g_diag_rec[slot];
     if (r.grid > max_wgs) return 3;
-    if (hipMemcpy(host, g_diag_buf + (size_t)slot * g_diag_max_wgs * 64, (size_t)r.grid * 512, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    if (hipMemcpy(host, g_diag_buf + (size_t)slot * g_diag_max_wgs * 128, (size_t)r.grid * 1024, hipMemcpyDeviceToHost) != hipSuccess) return 2;
     meta[0] = r.M; meta[1] = r.N; meta[2] = r.K; meta[3] = r.epi; meta[4] = r.f8; meta[5] = r.grid; meta[6] = r.variant;
     return 0;
 }
