@@ -321,7 +321,7 @@ __device__ __forceinline__ void ring_wait_dma() {
 // waits for is then younger than about five tiles: every wait is a COUNTED vmcnt that leaves the younger DMAs and the
 // previous item's output stores in flight.  Per DMA wave and item i (nt tiles, nw waves) the issue order is
 //   item top : slot nt-1 (i)                  2      tile 1 top: Q (i+1) nw, slot 0 (i+1) 2
-//   tile t top, t = 2..nt-1: slot t-1 (i+1)   2      item end  : 8 stores
+//   tile t top, t = 2..nt-1: slot t-1 (i+1)   2      item end  : 8 stores (NST in the code: 4 since round 3 for 16-bit results)
 // so a wait for X may leave outstanding:  item top (Q, slot 0): 2(nt-2) + 8;  tile 1 (slot 1): 2(nt-3) + 8 + 2;
 // tile t in 2..nt-2 (slot t): 2nt + nw + 4;  last tile (slot nt-1): nw + 2 + 2(nt-3).  The last item of a workgroup
 // issues no refills and waits with vmcnt(0).
@@ -438,8 +438,11 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
     if (!QS) load_q(item, qf);
     bool first = true;
     // QS: outstanding operations a wait may leave behind (see the table above)
-    const int w_top = 2 * (ntiles - 2) + 8, w_t1 = 2 * (ntiles - 3) + 10, w_mid = 2 * ntiles + nw + 4, w_last = nw + 2 + 2 * (ntiles - 3);
-    bool stored = false;   // did this wave issue the 8 stores of the previous item (wave-uniform)
+    // NST = output store instructions per wave and item: 4 x 16 bytes per lane for 16-bit results (the widened form at the
+    // item end), 8 x 4 bytes for e4m3.  Every "8" of the table above is NST here.
+    constexpr int NST = sizeof(typename TO::elem) == 2 ? 4 : 8;
+    const int w_top = 2 * (ntiles - 2) + NST, w_t1 = 2 * (ntiles - 3) + NST + 2, w_mid = 2 * ntiles + nw - 4 + NST, w_last = nw + 2 + 2 * (ntiles - 3);
+    bool stored = false;   // did this wave issue the NST stores of the previous item (wave-uniform)
 
 #ifdef VH_DIAG_STAMPS
     const unsigned long long rt0_ = attn_rt();
@@ -456,7 +459,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
         int next = QS ? item + stride : (last_slab ? (item / slabs + stride) * slabs : item + 1);
         if (QS && dyn && !first) {
             if (wave == nw - 1) {   // the ticket drawn at the top of the previous item (older than that item's 8 stores)
-                if (stored) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("" : "+v"(tkv));
                 if (lane == 0) *(volatile unsigned int __attribute__((address_space(3)))*)(uintptr_t)(lds0 + tk_off) = 2u * (unsigned)stride + tkv;
@@ -474,7 +477,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
             ring_wait_vm(first ? 0 : w_top);   // (everything it may leave behind was issued during the previous item)
         } else {
             if (first || !stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
             asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));   // uses of the Q fragments stay behind the wait
         }
         VH_ATT_T(0);   // item-top wait
@@ -657,7 +660,27 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
             const float ltot = cross_half_sum(lsum);
             const float inv = __builtin_amdgcn_rcpf(ltot);   // 1 ulp; the result is rounded to 16 (8) bits right after
             const int q = q0 + l31;
-            if (q < tokens) {
+            if constexpr (sizeof(typename TO::elem) == 2) {
+                // 16-bit output: the two halves of the wave hold the two quads of every 8-column group of a row, so the
+                // natural store is 8 x 8 bytes per lane.  One v_permlane32_swap per packed dword on a PAIR of groups
+                // (rg, rg + 1) leaves lanes 0-31 with the whole group rg and lanes 32-63 with the whole group rg + 1
+                // (cdna_hip_programming.md T21): 4 x 16 bytes per lane, half the store instructions for the same bytes --
+                // the phase is store-issue-bound (15 % of a wave's time in r02_c_attn_anatomy.txt).  The swaps run on every
+                // lane (no divergence around a cross-lane instruction); only the stores are predicated.
+                typename TO::elem* const op = out + ((int64_t)b * tokens + (q < tokens ? q : tokens - 1)) * D + h * 64 + 8 * hl;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const f32x16& o = db ? o1 : o0;
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg += 2) {
+                        const u32x2 ga = __builtin_bit_cast(u32x2, pack4<TO>(o[4 * rg] * inv, o[4 * rg + 1] * inv, o[4 * rg + 2] * inv, o[4 * rg + 3] * inv));
+                        const u32x2 gb = __builtin_bit_cast(u32x2, pack4<TO>(o[4 * rg + 4] * inv, o[4 * rg + 5] * inv, o[4 * rg + 6] * inv, o[4 * rg + 7] * inv));
+                        const auto sx = __builtin_amdgcn_permlane32_swap(ga[0], gb[0], false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(ga[1], gb[1], false, false);
+                        if (q < tokens) *(u32x4*)(op + 32 * db + 8 * rg) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+                    }
+                }
+            } else if (q < tokens) {
                 typename TO::elem* op = out + ((int64_t)b * tokens + q) * D + h * 64 + 4 * hl;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
