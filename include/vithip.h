@@ -253,6 +253,10 @@ int vh_debug_set_layers(vh_ctx* ctx, int n_layers);
 #define VH_EPI_RESID_SPLIT 8 /* residual kept as TWO 16-bit planes, x = hi + lo: (hi, lo) += acc + bias with hi = T(x), lo = T(x - hi);
                                 out = hi plane (the next GEMM's A operand), out16 = lo plane, partials as RESID_LN.  4 B per
                                 element each way instead of 4 B + the 2 B copy of RESID_LN */
+#define VH_EPI_PATCH_SPLIT 9 /* the patch embedding written directly as the split residual: row(m) of (hi, lo) = the planes of
+                                acc + bias + pos[tok(m)], plus that row's partial sums (partials[N/64][R][2], R = token rows) --
+                                EPI_PATCH and the first row-statistics pass in one epilogue.  out = hi, out16 = lo, aux /
+                                aux_i as EPI_PATCH; the class-token rows are not touched (vh_op_gemm_ex: R = images x tokens) */
 /* out = epilogue(A[M,K] * W[N,K]^T); A and W hold `dtype` elements, K contiguous.
  * aux: EPI_PATCH -> pos-emb fp32 [tokens, N] with aux_i = patches per image.
  * variant: 0 = auto, 1 = 128x128 tile, 2 = 256x256 two-stage, 5 = 256x256 ping-pong, 6 = persistent ping-pong. */

@@ -454,6 +454,46 @@ def test_gemm_resid_split_epilogue(dt, variant):
     assert np.abs(p[:, :, 1].T - (g64 ** 2).sum(2)).max() <= 1e-4 * (g64 ** 2).sum(2).max()
 
 
+@pytest.mark.parametrize("variant", [1, 2, 5, 6])
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("B,NP", [(3, 196), (37, 16), (5, 100)])
+def test_gemm_patch_split_epilogue(dt, variant, B, NP):
+    """VH_EPI_PATCH_SPLIT: the patch embedding written directly as the split residual.  Row m = image * NP + p of the GEMM
+    lands on token row image * (NP + 1) + 1 + p as hi = T(x), lo = T(x - hi) of x = A W^T + bias + pos[1 + p], with that
+    row's per-64-column (sum, sum of squares); class-token rows stay untouched (canary).  Patch counts above and below the
+    128-row wave tile (one or several image boundaries inside it), ragged M."""
+    N, K = 256, 192
+    T = NP + 1
+    M = B * NP
+    a = rnd16(S.fill(M * K, 41, 1, 0).reshape(M, K), dt)
+    w = rnd16(S.fill(N * K, 41, 2, 1, 0.1).reshape(N, K), dt)
+    bias = S.fill(N, 41, 3, 1, 0.1)
+    pos = S.fill(T * N, 41, 4, 1, 0.5).reshape(T, N)
+    ref = O.linear(a, w, bias).reshape(B, NP, N) + pos[None, 1:, :]
+    canary = np.full((B * T, N), 0x3c00 if dt == vithip.DTYPE_FP16 else 0x3f80, dtype=np.uint16)      # 1.0 everywhere
+    hi, lo = dev(canary), dev(canary)
+    parts = vithip.DeviceBuffer((N // 64) * B * T * 8)
+    pz = np.full((N // 64, B * T, 2), -7.0, dtype=np.float32)
+    vithip.lib().vh_memcpy_h2d(0, parts.ptr, pz.ctypes.data, pz.nbytes)
+    vithip.op_gemm_ex(dev(vithip.to16(a, dt)).ptr, dev(vithip.to16(w, dt)).ptr, dev(bias).ptr, hi.ptr, M, N, K,
+                      vithip.EPI_PATCH_SPLIT, dt, aux_ptr=dev(pos).ptr, aux_i=NP, out16_ptr=lo.ptr, partials_ptr=parts.ptr,
+                      variant=variant)
+    h16 = hi.to_numpy(np.uint16, (B, T, N))
+    l16 = lo.to_numpy(np.uint16, (B, T, N))
+    assert (h16[:, 0] == canary[0, 0]).all() and (l16[:, 0] == canary[0, 0]).all()          # class-token rows untouched
+    h, l = vithip.from16(h16, dt)[:, 1:], vithip.from16(l16, dt)[:, 1:]
+    got = h.astype(np.float64) + l
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= (2.0 ** -15 if dt == vithip.DTYPE_BF16 else 2.0 ** -20) * scale + 2e-5 * scale
+    assert (np.abs(h - ref) <= ULP[dt] * np.abs(ref) * 1.01 + 2e-5 * scale).all()
+    assert (np.abs(l) <= ULP[dt] * np.abs(h) * 1.0001 + 1e-30).all()                           # lo is a rounding residue: at most half an ulp of hi
+    p = parts.to_numpy(np.float32, (N // 64, B, T, 2))
+    assert (p[:, :, 0] == -7.0).all()                                                           # no statistics for class-token rows
+    g64 = got.reshape(B, NP, N // 64, 64)
+    assert np.abs(np.moveaxis(p[:, :, 1:, 0], 0, 2) - g64.sum(3)).max() <= 2e-4 * scale
+    assert np.abs(np.moveaxis(p[:, :, 1:, 1], 0, 2) - (g64 ** 2).sum(3)).max() <= 1e-4 * (g64 ** 2).sum(3).max()
+
+
 def test_rowstats_split_planes_and_statistics():
     for dt in DT:
         rows, dim = 333, 768

@@ -47,6 +47,7 @@ struct EpiArgs {
     const float* stats;  // LNFOLD: [M][2] = (mean, rstd) of every row
     void* out16;         // RESID_LN: 16-bit copy of the updated residual [M, N]
     float* partials;     // RESID_LN: [N/64][M][2] = per-64-column (sum, sum of squares)
+    int64_t prow;        // PATCH_SPLIT: row stride of `partials` (token rows); the other forms use M
 };
 
 constexpr bool epi_is_16bit(int epi) {
@@ -139,7 +140,7 @@ __device__ __forceinline__ f32x4 epi_value16(f32x4 acc, f32x4 bv, f32x4 cv, floa
 // ---- direct (unstaged) epilogue: ragged-N tiles, the patch-row remap, small kernels -----------------------
 template <typename T, int EPI, int MI, int NI, bool GUARD>
 __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m0, int n0) {
-    static_assert(EPI != VH_EPI_RESID_LN && EPI != VH_EPI_RESID_SPLIT, "RESID_LN / RESID_SPLIT need the staged path (N % tile == 0)");
+    static_assert(EPI != VH_EPI_RESID_LN && EPI != VH_EPI_RESID_SPLIT && EPI != VH_EPI_PATCH_SPLIT, "RESID_LN / RESID_SPLIT / PATCH_SPLIT need the staged path (N % tile == 0)");
     using elem = typename T::elem;
     const int M = e.M, N = e.N;
     f32x4 bv[NI], cv[NI];
@@ -287,33 +288,59 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 else if (MFULL || m < M) epi_store(v, (u32x4*)((elem*)e.out + (int64_t)m * N + n));
             }
         }
-    } else if constexpr (EPI == VH_EPI_RESID_SPLIT) {
+    } else if constexpr (EPI == VH_EPI_RESID_SPLIT || EPI == VH_EPI_PATCH_SPLIT) {
         // split residual: stage acc + bias as fp32 rows (256 B, chunk ^ (r & 15)) like the fp32 form, read back EIGHT columns per
-        // lane (two chunks), so that the hi and the lo plane are each accessed 16 B per lane / 128 B per row.  The planes of
-        // pass h+1 are loaded before pass h is processed (same reason as in the fp32 form below).
+        // lane (two chunks), so that the hi and the lo plane are each accessed 16 B per lane / 128 B per row.  What the row
+        // ADDS -- its own planes (RESID_SPLIT) or the position embedding's fp32 row (PATCH_SPLIT: the patch embedding lands
+        // directly in the split form, on the remapped row m + m / patches + 1, with the first row statistics) -- is loaded for
+        // pass h+1 before pass h is processed (same reason as in the fp32 form below).
         using vec8 = typename T::vec8;
+        constexpr bool PATCHS = EPI == VH_EPI_PATCH_SPLIT;
         constexpr int FMI = SMI / 2, NP = MI / FMI, NL = FMI * 2;
         const int rr = lane >> 3, pc = lane & 7;
         elem* const hi = (elem*)e.out;
         elem* const lo = (elem*)e.out16;
-        vec8 xh[2][NL], xl[2][NL];
-        auto where = [&](int h, int i, int& m) {
-            m = m_w + h * FMI * 16 + i * 8 + rr;
-            return (int64_t)m * N + n_w + 8 * pc;
+        const int64_t prow = PATCHS ? e.prow : (int64_t)M;
+        // 8 fp32 addends per lane and line: RESID_SPLIT converts its two 16-bit planes on use, PATCH_SPLIT loads them as is
+        struct Add { vec8 h, l; f32x4 p0, p1; };
+        Add xa[2][NL];
+        // PATCH_SPLIT: GEMM row m = image * patches + p lands on token row m + image + 1 and adds pos row 1 + p.  One scalar
+        // division per wave tile (m_w is wave-uniform), then a carry per row instead of a vector division per line.
+        const int q0 = PATCHS ? m_w / e.aux_i : 0, r0 = PATCHS ? m_w - q0 * e.aux_i : 0;
+        auto where = [&](int h, int i, int& m, int64_t& orow, int& p) {   // GEMM row m -> output row, element offset of the lane's 8 columns
+            const int dr = h * FMI * 16 + i * 8 + rr;
+            m = m_w + dr;
+            p = 0;
+            if constexpr (PATCHS) {
+                int img = q0;
+                p = r0 + dr;
+                while (p >= e.aux_i) { p -= e.aux_i; ++img; }
+                orow = (int64_t)m + img + 1;
+            } else {
+                orow = m;
+            }
+            return orow * N + n_w + 8 * pc;
         };
-        auto load_pass = [&](int h, vec8 (&a)[NL], vec8 (&b)[NL]) {
+        auto load_pass = [&](int h, Add (&a)[NL]) {
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
-                int m;
-                const int64_t off = where(h, i, m);
-                if (m < M && !(VH_EPI_ABL & 8)) { a[i] = *(const vec8*)(hi + off); b[i] = *(const vec8*)(lo + off); }
-                else { a[i] = vec8{}; b[i] = vec8{}; }
+                int m, p;
+                int64_t orow;
+                const int64_t off = where(h, i, m, orow, p);
+                if constexpr (PATCHS) {
+                    const float* pr = e.aux + (int64_t)(1 + p) * N + n_w + 8 * pc;   // (a row of the table whatever m is: no bound to check)
+                    a[i].p0 = *(const f32x4*)pr;
+                    a[i].p1 = *(const f32x4*)(pr + 4);
+                } else {
+                    if (m < M && !(VH_EPI_ABL & 8)) { a[i].h = *(const vec8*)(hi + off); a[i].l = *(const vec8*)(lo + off); }
+                    else { a[i].h = vec8{}; a[i].l = vec8{}; }
+                }
             }
         };
-        load_pass(0, xh[0], xl[0]);
+        load_pass(0, xa[0]);
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
-            if (h + 1 < NP) load_pass(h + 1, xh[(h + 1) & 1], xl[(h + 1) & 1]);
+            if (h + 1 < NP) load_pass(h + 1, xa[(h + 1) & 1]);
 #pragma unroll
             for (int mi = 0; mi < FMI; ++mi) {
                 const int r = mi * 16 + frow;
@@ -326,16 +353,19 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 const int r = i * 8 + rr;
                 const f32x4 v0 = *(const f32x4*)(sw + r * 256 + (((2 * pc) ^ (r & 15)) << 4));
                 const f32x4 v1 = *(const f32x4*)(sw + r * 256 + (((2 * pc + 1) ^ (r & 15)) << 4));
-                int m;
-                const int64_t off = where(h, i, m);
+                int m, p;
+                int64_t orow;
+                const int64_t off = where(h, i, m, orow, p);
                 const bool ok = m < M;
+                const Add& a = xa[h & 1][i];
                 float v[8];
                 vec8 hn, ln;
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    // hi + lo is exact in fp32 (at most 17 / 23 significant bits), then ONE rounding of the sum with the update
-                    v[j] = (j < 4 ? v0[j] : v1[j - 4]) + ((float)xh[h & 1][i][j] + (float)xl[h & 1][i][j]);
+                    // RESID_SPLIT: hi + lo is exact in fp32 (at most 17 / 23 significant bits), then ONE rounding of the sum with the update
+                    const float add = PATCHS ? (j < 4 ? a.p0[j] : a.p1[j - 4]) : ((float)a.h[j] + (float)a.l[j]);
+                    v[j] = (j < 4 ? v0[j] : v1[j - 4]) + add;
                     hn[j] = (elem)v[j];
                     ln[j] = (elem)(v[j] - (float)hn[j]);
                     s1 += v[j];
@@ -346,7 +376,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);     // quad_perm [1,0,3,2]
                 s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);     // quad_perm [2,3,0,1]
                 s1 += dpp_mov<0x141>(s1); s2 += dpp_mov<0x141>(s2);   // row_half_mirror
-                if (ok && pc == 0 && !(VH_EPI_ABL & 1)) *(float2*)(e.partials + 2 * ((int64_t)(n_w >> 6) * M + m)) = make_float2(s1, s2);
+                if (ok && pc == 0 && !(VH_EPI_ABL & 1)) *(float2*)(e.partials + 2 * ((int64_t)(n_w >> 6) * prow + orow)) = make_float2(s1, s2);
             }
         }
     } else {
@@ -416,14 +446,14 @@ template <typename T, int EPI, int MI, int NI, int SMI = MI, bool BARRIER = true
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w, int lane,
                                               bool n_full, bool m_full, char* smem, int wave) {
     if constexpr (EPI != VH_EPI_PATCH) {
-        if (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT || n_full) {
+        if (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT || EPI == VH_EPI_PATCH_SPLIT || n_full) {
             if constexpr (BARRIER) __syncthreads();
             if (m_full && epi_is_16bit(EPI)) gemm_epilogue_staged<T, EPI, MI, NI, SMI, true>(acc, e, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
             else gemm_epilogue_staged<T, EPI, MI, NI, SMI, false>(acc, e, m_w, n_w, lane, smem + wave * (SMI * 16 * 128));
             return;
         }
     }
-    if constexpr (EPI != VH_EPI_RESID_LN && EPI != VH_EPI_RESID_SPLIT) {
+    if constexpr (EPI != VH_EPI_RESID_LN && EPI != VH_EPI_RESID_SPLIT && EPI != VH_EPI_PATCH_SPLIT) {
         const int m0 = m_w + (lane & 15), n0 = n_w + (lane >> 4) * 4;
         if (n_full && m_full) gemm_epilogue_impl<T, EPI, MI, NI, false>(acc, e, m0, n0);
         else gemm_epilogue_impl<T, EPI, MI, NI, true>(acc, e, m0, n0);

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(WM* WN * 64)
 gemm_nt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* __restrict__ W,
                const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
-               void* __restrict__ out16, float* __restrict__ partials) {
+               void* __restrict__ out16, float* __restrict__ partials, int64_t prow) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
     constexpr int NW = WM * WN;
@@ -130,7 +130,7 @@ gemm_nt_kernel(const typename T::elem* __restrict__ A, const typename T::elem* _
     }
 
     // ---- epilogue: lane owns rows m = .. + (lane&15), 4 consecutive columns n = .. + 4*(lane>>4)
-    const EpiArgs e{bias, outp, M, N, aux, aux_i, stats, out16, partials};
+    const EpiArgs e{bias, outp, M, N, aux, aux_i, stats, out16, partials, prow};
     gemm_epilogue<T, EPI, MI, NI>(acc, e, tile_m * BM + wm * TM, tile_n * BN + wn * TN, lane, (tile_n + 1) * BN <= N,
                                   (tile_m + 1) * BM <= M, smem, wave);
 }
@@ -145,7 +145,7 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s) {
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, s,
                        (const typename T::elem*)g.a, (const typename T::elem*)g.w, g.bias, g.out,
-                       (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n, g.stats, g.out16, g.partials);
+                       (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m, tiles_n, g.stats, g.out16, g.partials, gemm_prow(g));
     return hipGetLastError();
 }
 
@@ -171,6 +171,7 @@ static hipError_t launch_epi(const GemmArgs& g, int variant, hipStream_t s) {
     case VH_EPI_LNFOLD_GELU: return launch_tile<T, VH_EPI_LNFOLD_GELU>(g, variant, s);
     case VH_EPI_RESID_LN: return launch_tile<T, VH_EPI_RESID_LN>(g, variant, s);
     case VH_EPI_RESID_SPLIT: return launch_tile<T, VH_EPI_RESID_SPLIT>(g, variant, s);
+    case VH_EPI_PATCH_SPLIT: return launch_tile<T, VH_EPI_PATCH_SPLIT>(g, variant, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -198,11 +199,13 @@ const char* gemm_check(const GemmArgs& g) {
     if (g.K % 64) return "gemm: K must be a multiple of 64";
     if (g.N % 4) return "gemm: N must be a multiple of 4";
     if (g.M > 0x7fffffff) return "gemm: M too large";
-    if (g.epilogue < 0 || g.epilogue > VH_EPI_RESID_SPLIT) return "gemm: unknown epilogue";
+    if (g.epilogue < 0 || g.epilogue > VH_EPI_PATCH_SPLIT) return "gemm: unknown epilogue";
     if ((g.epilogue == VH_EPI_LNFOLD || g.epilogue == VH_EPI_LNFOLD_GELU) && (!g.stats || !g.aux)) return "gemm: LNFOLD needs stats and c (aux)";
     if ((g.epilogue == VH_EPI_RESID_LN || g.epilogue == VH_EPI_RESID_SPLIT) && (!g.out16 || !g.partials || g.N % 256))
         return "gemm: RESID_LN / RESID_SPLIT need out16, partials and N % 256 == 0";
     if (g.epilogue == VH_EPI_PATCH && (!g.aux || g.aux_i <= 0)) return "gemm: EPI_PATCH needs pos-emb and patches/image";
+    if (g.epilogue == VH_EPI_PATCH_SPLIT && (!g.aux || g.aux_i <= 0 || !g.out16 || !g.partials || g.N % 256 || g.prow < 0))
+        return "gemm: EPI_PATCH_SPLIT needs pos-emb, patches/image, the lo plane, partials and N % 256 == 0";
     if (g.dtype != VH_DTYPE_BF16 && g.dtype != VH_DTYPE_FP16) return "gemm: dtype";
     if (g.variant < 0 || g.variant > 7) return "gemm: variant";
     if (g.variant == 3 || g.variant == 4) return "gemm: variants 3/4 (BK=32 pipeline) were removed";

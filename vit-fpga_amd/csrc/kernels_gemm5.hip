@@ -117,7 +117,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
                   const float* __restrict__ aux, int aux_i, int tiles_m, int tiles_n, const float* __restrict__ stats,
                   void* __restrict__ out16, float* __restrict__ partials, int tile0, int sn,
-                  const float* __restrict__ wscale VH_STAMP_PARAM) {
+                  const float* __restrict__ wscale, int64_t prow VH_STAMP_PARAM) {
     using vec8 = typename T::vec8;
 #ifdef VH_DIAG_STAMPS
     // the iteration whose stamps are kept: the workgroup's only tile, or the SECOND tile of a persistent workgroup
@@ -396,7 +396,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         const bool m_full = (tile_m + 1) * BM <= M, n_full = (tile_n + 1) * BN <= N;
         // one tile per workgroup: the epilogue stages through the (idle) stage 1; persistent: through its own region
         char* const stage_epi = smem + (PERSIST ? 2 * STAGE_BYTES : STAGE_BYTES);
-        const EpiArgs e{bias, outp, M, N, aux, aux_i, stats, out16, partials};
+        const EpiArgs e{bias, outp, M, N, aux, aux_i, stats, out16, partials, prow};
         // Everything the epilogue derives from the lane id is derived HERE, per tile: in the persistent form the compiler
         // would otherwise hoist those lane-constant addresses out of the tile loop and keep them alive through the K loop,
         // which has no register to spare (spills inside the K loop are vector-memory operations: they would break its
@@ -501,7 +501,7 @@ static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int ti
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
                        tiles_n, g.stats, g.out16, g.partials, PERSIST ? 0 : g.tile_begin, (g.tile_count || g.tile_begin) ? 0 : gemm_super_columns(tiles_n),
-                       F8 ? (g.wscale ? g.wscale : g.aux) : (const float*)nullptr
+                       F8 ? (g.wscale ? g.wscale : g.aux) : (const float*)nullptr, gemm_prow(g)
                        VH_STAMP_ARG(g, EPI, F8, grid, PERSIST ? 6 : (AST == 3 ? 7 : 5)));
     return hipGetLastError();
 }
@@ -557,7 +557,8 @@ hipError_t launch_gemm_pingpong(const GemmArgs& g, int mode, hipStream_t s) {
     template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD>(const GemmArgs&, int, hipStream_t);      \
     template hipError_t launch_gemm_pingpong<T, VH_EPI_LNFOLD_GELU>(const GemmArgs&, int, hipStream_t); \
     template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_LN>(const GemmArgs&, int, hipStream_t);   \
-    template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_SPLIT>(const GemmArgs&, int, hipStream_t);
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_RESID_SPLIT>(const GemmArgs&, int, hipStream_t); \
+    template hipError_t launch_gemm_pingpong<T, VH_EPI_PATCH_SPLIT>(const GemmArgs&, int, hipStream_t);
 VH_INST(BF16)
 VH_INST(FP16)
 

@@ -128,6 +128,43 @@ hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int bat
     return hipGetLastError();
 }
 
+// the same rows for the SPLIT residual (PATCH_SPLIT path): planes hi = T(x), lo = T(x - hi) of x = cls + pos[0], and the
+// row's (sum, sum of squares) per 64-column block -- what the patch GEMM's epilogue writes for every other row.  One wave
+// per image; a lane owns column 64 * blk + lane of every block; fixed-order butterfly sums.
+template <typename T>
+__global__ void __launch_bounds__(256)
+cls_rows_split_kernel(typename T::elem* __restrict__ hi, typename T::elem* __restrict__ lo, float* __restrict__ partials, int64_t prow,
+                      const float* __restrict__ cls, const float* __restrict__ pos, int batch, int tokens, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const int64_t row = (int64_t)b * tokens;
+    for (int blk = 0; blk * 64 < dim; ++blk) {
+        const int d = blk * 64 + lane;
+        float v = 0.f;
+        if (d < dim) {
+            v = cls[d] + pos[d];
+            const typename T::elem h = (typename T::elem)v;
+            hi[row * dim + d] = h;
+            lo[row * dim + d] = (typename T::elem)(v - (float)h);
+        }
+        float s1 = v, s2 = v * v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (lane == 0) *(float2*)(partials + 2 * ((int64_t)blk * prow + row)) = make_float2(s1, s2);
+    }
+}
+hipError_t launch_cls_rows_split(void* hi, void* lo, float* partials, int64_t prow, const float* cls, const float* pos, int batch,
+                                 int tokens, int dim, int dtype, hipStream_t s) {
+    if (batch <= 0 || dim % 64) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((batch + 3) / 4));
+    if (dtype == VH_DTYPE_BF16)
+        hipLaunchKernelGGL(cls_rows_split_kernel<BF16>, grid, dim3(256), 0, s, (BF16::elem*)hi, (BF16::elem*)lo, partials, prow, cls, pos, batch, tokens, dim);
+    else
+        hipLaunchKernelGGL(cls_rows_split_kernel<FP16>, grid, dim3(256), 0, s, (FP16::elem*)hi, (FP16::elem*)lo, partials, prow, cls, pos, batch, tokens, dim);
+    return hipGetLastError();
+}
+
 // ---- fp32 -> 16-bit cast -----------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) cast_kernel(const float* __restrict__ in, typename T::elem* __restrict__ out, int64_t n4) {

@@ -29,7 +29,16 @@ struct GemmArgs {
     // (tile t = (t / tiles_n, t % tiles_n)); tile_count == 0 = all tiles.  Lets a caller split off the last, partly
     // filled round of tiles and overlap it with other work (vithip_api.hip, tail overlap).
     int tile_begin = 0, tile_count = 0;
+    // PATCH_SPLIT: row stride of `partials` = number of TOKEN rows the statistics buffer is laid out for (0 = images x tokens)
+    int64_t prow = 0;
 };
+
+// row stride of the partial-sum buffer a launch writes: PATCH_SPLIT lands on token rows (images x (patches + 1) unless the
+// caller's buffer is laid out for more, e.g. rows padded to whole tiles); the other forms use their own M inside the kernel
+inline int64_t gemm_prow(const GemmArgs& g) {
+    if (g.epilogue != VH_EPI_PATCH_SPLIT) return g.M;
+    return g.prow > 0 ? g.prow : (g.M / g.aux_i) * (int64_t)(g.aux_i + 1);
+}
 
 // every launcher only enqueues on `stream`; returns hipSuccess or the launch error
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t stream);
@@ -60,6 +69,9 @@ hipError_t launch_im2col(const float* in_nhwc, int batch, int image, int patch, 
                          void* out16, int dtype, hipStream_t stream);
 hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int batch, int tokens,
                            int dim, hipStream_t stream);
+// the class-token rows of the SPLIT residual: (hi, lo) planes of cls + pos[0] and their per-64-column partial sums
+hipError_t launch_cls_rows_split(void* hi, void* lo, float* partials, int64_t prow, const float* cls, const float* pos, int batch,
+                                 int tokens, int dim, int dtype, hipStream_t stream);
 hipError_t launch_cast(const float* in, void* out16, int64_t n, int dtype, hipStream_t stream);
 hipError_t launch_fill(float* out, int64_t n, uint64_t seed, uint32_t tensor_id, int kind,
                        float sigma, float offset, hipStream_t stream);

@@ -451,17 +451,32 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     if ((rc = mark(-1))) return rc;
     HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, col16, dt16, s));
     if ((rc = mark(ST_IM2COL))) return rc;
-    HIPCHK(&c->err, gemm(col16, c->wp16, P + L.patch_b, x, (int64_t)batch * L.NP, D, L.KP, VH_EPI_PATCH, P + L.pos, L.NP));
-    if ((rc = mark(ST_PATCH))) return rc;
-    HIPCHK(&c->err, launch_cls_rows(x, P + L.cls, P + L.pos, batch, T, D, s));
-    if ((rc = mark(ST_CLS))) return rc;
     const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
-    if (c->ln_fold && nl > 0) {
-        // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
-        if (c->split) HIPCHK(&c->err, launch_rowstats_split(x, rows_g, D, f.ln_eps, xn16, xlo16, stats_p, dt16, s));
-        else HIPCHK(&c->err, launch_rowstats_cast(x, rows_g, D, f.ln_eps, xn16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s));
-        HIPCHK(&c->err, launch_ln_guard(stats_p, rows, c->guard_dev, s));   // real rows only (rows_g - rows are tile padding)
+    if (c->split && nl > 0) {
+        // Split residual: the patch embedding lands DIRECTLY in the two 16-bit planes, with the first row statistics'
+        // partial sums (PATCH_SPLIT epilogue; the class-token rows from their own small kernel) -- no fp32 x, no separate
+        // row-statistics pass over it (round 3: -0.1 ms per forward).  The partial sums are laid out for rows_g rows, like
+        // every later layer's.
+        GemmArgs g{col16, c->wp16, P + L.patch_b, xn16, (int64_t)batch * L.NP, D, L.KP, VH_EPI_PATCH_SPLIT, P + L.pos, L.NP, dt16, 0};
+        g.out16 = xlo16; g.partials = partials_p; g.prow = rows_g;
+        HIPCHK(&c->err, launch_gemm(g, s));
+        if ((rc = mark(ST_PATCH))) return rc;
+        HIPCHK(&c->err, launch_cls_rows_split(xn16, xlo16, partials_p, rows_g, P + L.cls, P + L.pos, batch, T, D, dt16, s));
+        if ((rc = mark(ST_CLS))) return rc;
+        HIPCHK(&c->err, launch_finalize_stats(partials_p, D / 64, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev));
         if ((rc = mark(ST_LNSTATS))) return rc;
+    } else {
+        HIPCHK(&c->err, gemm(col16, c->wp16, P + L.patch_b, x, (int64_t)batch * L.NP, D, L.KP, VH_EPI_PATCH, P + L.pos, L.NP));
+        if ((rc = mark(ST_PATCH))) return rc;
+        HIPCHK(&c->err, launch_cls_rows(x, P + L.cls, P + L.pos, batch, T, D, s));
+        if ((rc = mark(ST_CLS))) return rc;
+        if (c->ln_fold && nl > 0) {
+            // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
+            if (c->split) HIPCHK(&c->err, launch_rowstats_split(x, rows_g, D, f.ln_eps, xn16, xlo16, stats_p, dt16, s));
+            else HIPCHK(&c->err, launch_rowstats_cast(x, rows_g, D, f.ln_eps, xn16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s));
+            HIPCHK(&c->err, launch_ln_guard(stats_p, rows, c->guard_dev, s));   // real rows only (rows_g - rows are tile padding)
+            if ((rc = mark(ST_LNSTATS))) return rc;
+        }
     }
     for (int l = 0; l < nl && c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
@@ -1609,8 +1624,8 @@ int vh_bench_gemm(int device, int64_t M, int N, int K, int epilogue, int dtype, 
     // the layer epilogues of the folded path: LNFOLD* read per-row (mean, rstd) and c_n (`aux`), RESID_LN / RESID_SPLIT
     // write a second 16-bit plane and the per-64-column row sums
     const bool fold = epilogue == VH_EPI_LNFOLD || epilogue == VH_EPI_LNFOLD_GELU;
-    const bool resid2 = epilogue == VH_EPI_RESID_LN || epilogue == VH_EPI_RESID_SPLIT;
-    const size_t out_rows = epilogue == VH_EPI_PATCH ? (size_t)(M / aux_i + 1) * (aux_i + 1) : (size_t)M;
+    const bool resid2 = epilogue == VH_EPI_RESID_LN || epilogue == VH_EPI_RESID_SPLIT || epilogue == VH_EPI_PATCH_SPLIT;
+    const size_t out_rows = (epilogue == VH_EPI_PATCH || epilogue == VH_EPI_PATCH_SPLIT) ? (size_t)(M / aux_i + 1) * (aux_i + 1) : (size_t)M;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
         hipFree(a32); hipFree(w32); hipFree(bias); hipFree(aux); hipFree(a16); hipFree(w16); hipFree(out);
@@ -1640,9 +1655,10 @@ int vh_bench_gemm(int device, int64_t M, int N, int K, int epilogue, int dtype, 
         g.stats = stats;
     }
     if (resid2) {
-        BCHK(hipMalloc(&out16, (size_t)M * N * 2));
-        BCHK(hipMemset(out16, 0, (size_t)M * N * 2));
-        BCHK(hipMalloc((void**)&partials, (size_t)((N + 63) / 64) * M * 2 * 4));
+        BCHK(hipMalloc(&out16, out_rows * N * 2));
+        BCHK(hipMemset(out16, 0, out_rows * N * 2));
+        BCHK(hipMalloc((void**)&partials, (size_t)((N + 63) / 64) * out_rows * 2 * 4));
+        if (epilogue == VH_EPI_PATCH_SPLIT) g.prow = (int64_t)out_rows;
         g.out16 = out16;
         g.partials = partials;
     }
