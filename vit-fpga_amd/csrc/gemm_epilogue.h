@@ -198,22 +198,6 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
     }
 }
 
-// Hook: a callable the staged epilogues invoke exactly ONCE at the point where none of their own global loads is still
-// outstanding or still to be consumed from an earlier issue: the persistent GEMM hands in the LDS-DMA prefetch of its
-// NEXT tile there.  vmcnt retires in order, so a load consumed AFTER a DMA that was issued behind it would wait for the
-// DMA as well (and hipcc 7.2 waits vmcnt(0), not a counted value, for any ordinary load while a DMA is in flight):
-// the hook therefore sits behind an explicit vmcnt(0) that both the hardware and the compiler's scoreboard see.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <typename Hook> struct is_no_hook { static constexpr bool value = false; };
-template <> struct is_no_hook<NoHook> { static constexpr bool value = true; };
-template <typename Hook>
-__device__ __forceinline__ void run_hook(const Hook& hook) {
-    if constexpr (!is_no_hook<Hook>::value) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every load issued so far has landed
-        hook();
-    }
-}
-
 // ---- LDS-staged epilogue -------------------------------------------------------------------------------
 // The accumulator layout gives a lane 4 consecutive columns of 16 different rows, so a direct store
 // instruction touches 16 rows x 32 B (16-bit out) or x 64 B (fp32): partial lines, measured 3.5x slower than
@@ -224,9 +208,9 @@ __device__ __forceinline__ void run_hook(const Hook& hook) {
 // SMI = 16-row blocks staged per pass for 16-bit output (slice = SMI * 2 KiB per wave); fp32 stages SMI/2.
 // MFULL: every row of the wave's sub-tile is inside M (all but the last row tile of a GEMM): the 16-bit store loop then
 // carries no per-row predicate, so the read-backs of a pass are issued together instead of one per predicated block.
-template <typename T, int EPI, int MI, int NI, int SMI = MI, bool MFULL = false, typename Hook = NoHook>
+template <typename T, int EPI, int MI, int NI, int SMI = MI, bool MFULL = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w,
-                                                     int lane, char* sw, const Hook& hook = Hook()) {
+                                                     int lane, char* sw) {
     static_assert(NI == 4, "staged epilogue assumes a 64-column wave tile");
     static_assert(MI % SMI == 0 && SMI % 2 == 0, "slice must divide the wave tile");
     using elem = typename T::elem;
@@ -259,7 +243,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
             }
         }
-        run_hook(hook);   // bias / c / statistics are the only loads of this form: all issued above
 #pragma unroll
         for (int h = 0; h < MI / SMI; ++h) {
 #pragma unroll
@@ -415,7 +398,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 for (int ni = 0; ni < NI; ++ni)
                     *(f32x4*)(sw + r * 256 + (((ni * 4 + fq) ^ (r & 15)) << 4)) = acc[h * FMI + mi][ni] + bv[ni];
             }
-            if (h == NP - 1) run_hook(hook);   // the last pass's residual values were loaded a pass ago: nothing is issued after this
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
                 const int r = i * 4 + rr;
@@ -464,9 +446,9 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const 
 // A lane's accumulator quad is 4 consecutive columns = one dword of e4m3.  Staged like the 16-bit form: the
 // wave's 64-column rows are 64 B = 4 chunks of 16 B, chunk c of row r at position c ^ ((r >> 1) & 3); read back
 // 16 B per lane, 4 lanes per row, and stored as whole 64-B row segments.  Ragged tiles store dwords directly.
-template <int EPI, int MI, int NI, int SMI, bool MFULL = false, typename Hook = NoHook>
+template <int EPI, int MI, int NI, int SMI, bool MFULL = false>
 __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w, int lane,
-                                               bool n_full, char* smem, int wave, const Hook& hook = Hook()) {
+                                               bool n_full, char* smem, int wave) {
     static_assert(NI == 4 && MI % SMI == 0, "64-column wave tile");
     static_assert(EPI == VH_EPI_BIAS || EPI == VH_EPI_BIAS_GELU || EPI == VH_EPI_LNFOLD_GELU, "8-bit output: bias, bias+GELU or LN-fold+GELU");
     const int M = e.M, N = e.N;
@@ -477,7 +459,7 @@ __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const
         f32x4 v = epi_value16<EPI>(a, b, cq, mean_rstd, rstd);
         return pack4_e4m3(v[0], v[1], v[2], v[3]);
     };
-    if (n_full || !is_no_hook<Hook>::value || epi_is_lnfold(EPI)) {   // with a hook (persistent GEMM) / LN fold: staged form only, N % tile == 0 guaranteed
+    if (n_full || epi_is_lnfold(EPI)) {   // LN fold: staged form only, N % tile == 0 guaranteed
         f32x4 bv[NI], cv[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -494,7 +476,6 @@ __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const
                 lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
             }
         }
-        run_hook(hook);
         char* sw = smem + wave * (SMI * 16 * 128);
         const int rr = lane >> 2, pc = lane & 3;
 #pragma unroll
@@ -523,7 +504,7 @@ __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const
         }
         return;
     }
-    if constexpr (is_no_hook<Hook>::value && !epi_is_lnfold(EPI)) {
+    if constexpr (!epi_is_lnfold(EPI)) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int n = n_w + ni * 16 + fq * 4;

@@ -722,7 +722,7 @@ extern "C" int vh_diag_attn_read(unsigned long long* host, int n_words) {
 size_t attention_lds_bytes(int tokens) { return (size_t)((tokens + 31) / 32) * 8192; }
 
 template <typename T, typename TO = T>
-static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, unsigned int* ticket, hipStream_t s) {
+static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, unsigned int* ticket, hipStream_t s, bool tk_zeroed) {
     const int ntiles = (tokens + 31) / 32;
     const int nqb = ntiles;
     // waves per workgroup (each owns 32 queries): VH_ATTN_WAVES, default 16 (T = 577: 10 waves share one K/V image instead of 7)
@@ -754,7 +754,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
         const int grid = nitems < 2 * num_cu ? nitems : 2 * num_cu;
         static const int want_dyn = env_int("VH_ATTN_DYN", 1);   // VH_ATTN_DYN=0: equal static shares
         unsigned int* tk = want_dyn && nw >= 5 && nitems > 2 * grid ? ticket : nullptr;
-        if (tk) { if (hipError_t e = hipMemsetAsync(tk, 0, sizeof(unsigned int), s); e != hipSuccess) return e; }
+        if (tk && !tk_zeroed) { if (hipError_t e = hipMemsetAsync(tk, 0, sizeof(unsigned int), s); e != hipSuccess) return e; }
         const unsigned int heads_rcp = (unsigned int)(((1ull << 32) + (unsigned)heads - 1) / (unsigned)heads);
         hipLaunchKernelGGL(k, dim3(grid), dim3(nw * 64), qs_lds, s, (const typename T::elem*)qkv, (typename TO::elem*)out,
                            tokens, heads, slabs, ntiles, nitems, tk, heads_rcp);
@@ -800,11 +800,11 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
 }
 
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype,
-                            unsigned int* ticket, hipStream_t s) {
+                            unsigned int* ticket, hipStream_t s, bool ticket_zeroed) {
     if (batch <= 0 || tokens <= 0 || heads <= 0) return hipErrorInvalidValue;
-    if (dtype == VH_DTYPE_FP8) return launch_attn_t<BF16, E4M3>(qkv16, batch, tokens, heads, out16, ticket, s);  // bf16 in, e4m3 out
-    return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16>(qkv16, batch, tokens, heads, out16, ticket, s)
-                                  : launch_attn_t<FP16>(qkv16, batch, tokens, heads, out16, ticket, s);
+    if (dtype == VH_DTYPE_FP8) return launch_attn_t<BF16, E4M3>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed);  // bf16 in, e4m3 out
+    return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed)
+                                  : launch_attn_t<FP16>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed);
 }
 
 }  // namespace vh

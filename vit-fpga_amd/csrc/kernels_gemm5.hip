@@ -56,6 +56,10 @@
 
 namespace vh {
 
+#ifndef VH_MAIN_ABL
+#define VH_MAIN_ABL 0   // timing-only ablation builds (tools/build_abl.sh), 16-bit form: 1 no MFMAs, 2 no fragment reads, 4 fragment
+                        // reads in the workgroup's first K-tile only (real operands, then none), 8 no DMA after the prologue, 16 no barriers, 32 no s_setprio(1)
+#endif
 // ---- DIAGNOSTIC BUILD ONLY (-DVH_DIAG_STAMPS -> libvithip_diag.so, tools/gemm_anatomy.py) ---------------------------
 // Wave 0 of every workgroup stamps s_memrealtime (100 MHz, chip-wide) at: kernel entry, first K-tile visible, end of
 // the main loop, epilogue issued, stores drained; s_memtime (shader clock) around the main loop (in-kernel clock =
@@ -103,6 +107,9 @@ __device__ __forceinline__ void pp_wait_vmcnt() {
 }
 __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
+#if VH_MAIN_ABL & 16   // (with 12 only: no memory operation is left to order) the two waves of a SIMD issue as they come
+    return;
+#endif
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -197,7 +204,9 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     int par = 0;
     auto a_off = [&](int kt, int kt3) { return AST == 2 ? ((par + kt) & 1) * STAGE_BYTES : 2 * W_OFF + kt3 * 32768; };
     auto w_off = [&](int kt) { return AST == 2 ? ((par + kt) & 1) * STAGE_BYTES + W_OFF : (kt & 1) * W_OFF; };
+    bool dma_on = true;   // VH_MAIN_ABL & 8 only
     auto dma4 = [&](const char* base, const uint32_t (&off)[4], char* dst) {
+        if constexpr (VH_MAIN_ABL & 8) { if (!dma_on) return; }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + off[i]),
@@ -227,6 +236,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     if (nk > 1) pp_wait_vmcnt<8>();  // K-tile 0 landed, K-tile 1 may fly
     else pp_wait_vmcnt<0>();
     pp_barrier();                    // K-tile 0 visible
+    if constexpr (VH_MAIN_ABL & 8) dma_on = false;
 
     // Persistent form (nk >= 2, full tiles only: the launcher sees to both): the DMA stream does not stop at a tile
     // boundary.  The slots of the schedule that would fetch K-tiles nk and nk + 1 of the current tile fetch K-tiles 0 and
@@ -346,40 +356,56 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // ---- L0 ------------------------------------------------------------------------------------------------
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
+                if constexpr (VH_MAIN_ABL & 2) { asm volatile("" : "=v"(wf0[ni])); asm volatile("" : "=v"(wf1[ni])); continue; }
+                if constexpr (VH_MAIN_ABL & 4) { if (!(first && kt == 0)) { asm volatile("" : "+v"(wf0[ni])); asm volatile("" : "+v"(wf1[ni])); continue; } }
                 wf0[ni] = *(const vec8*)(sw + ni * 2048 + off0);
                 wf1[ni] = *(const vec8*)(sw + ni * 2048 + off1);
             }
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(sa + mi * 2048 + off0);
+            for (int mi = 0; mi < MI; ++mi) {
+                if constexpr (VH_MAIN_ABL & 2) { asm volatile("" : "=v"(xf[mi])); continue; }
+                if constexpr (VH_MAIN_ABL & 4) { if (!(first && kt == 0)) { asm volatile("" : "+v"(xf[mi])); continue; } }
+                xf[mi] = *(const vec8*)(sa + mi * 2048 + off0);
+            }
             l0_issue(kt, k3);
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
             VH_PSTAMP(1);
             pp_barrier();
             VH_PSTAMP(2);
             // ---- C0 ------------------------------------------------------------------------------------------------
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr (!(VH_MAIN_ABL & 32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf0[ni], xf[mi], acc[mi][ni]);
+                for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (VH_MAIN_ABL & 1) asm volatile("" : "+v"(acc[mi][ni]) : "v"(wf0[ni]), "v"(xf[mi]));
+                    else acc[mi][ni] = T::mfma16(wf0[ni], xf[mi], acc[mi][ni]);
+                }
             __builtin_amdgcn_s_setprio(0);
             VH_PSTAMP(3);
             pp_barrier();
             VH_PSTAMP(4);
             // ---- L1 ------------------------------------------------------------------------------------------------
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const vec8*)(sa + mi * 2048 + off1);
+            for (int mi = 0; mi < MI; ++mi) {
+                if constexpr (VH_MAIN_ABL & 2) { asm volatile("" : "=v"(xf[mi])); continue; }
+                if constexpr (VH_MAIN_ABL & 4) { asm volatile("" : "+v"(xf[mi])); continue; }
+                xf[mi] = *(const vec8*)(sa + mi * 2048 + off1);
+            }
             l1_issue_wait(kt);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             VH_PSTAMP(5);
             pp_barrier();
             VH_PSTAMP(6);
             // ---- C1 ------------------------------------------------------------------------------------------------
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr (!(VH_MAIN_ABL & 32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = T::mfma16(wf1[ni], xf[mi], acc[mi][ni]);
+                for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (VH_MAIN_ABL & 1) asm volatile("" : "+v"(acc[mi][ni]) : "v"(wf1[ni]), "v"(xf[mi]));
+                    else acc[mi][ni] = T::mfma16(wf1[ni], xf[mi], acc[mi][ni]);
+                }
             __builtin_amdgcn_s_setprio(0);
             c1_wait(kt);
             VH_PSTAMP(7);

@@ -60,10 +60,11 @@ hipError_t launch_head_f32(const float* y, const float* w, const float* bias, fl
 // q columns of qkv16 arrive scaled by kAttnQScale = 64^-1/2 * log2(e) (folded into Wq and bq when the weights are
 // prepared): the score MFMAs then produce log2-domain scores and the softmax is exp2 without a multiply per score
 constexpr float kAttnQScale = 0.125f * 1.4426950408889634f;
-// ticket: 4 bytes of device scratch owned by the caller's stream (zeroed by the launch; work-queue counter of the
-// staged ring form), or nullptr for equal static shares per workgroup
+// ticket: 4 bytes of device scratch owned by the caller's stream (work-queue counter of the staged ring form; zeroed by
+// the launch unless the caller says it already is: a forward zeroes one word per layer with ONE memset), or nullptr for
+// equal static shares per workgroup
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16,
-                            int dtype, unsigned int* ticket, hipStream_t stream);
+                            int dtype, unsigned int* ticket, hipStream_t stream, bool ticket_zeroed = false);
 size_t attention_lds_bytes(int tokens);
 hipError_t launch_im2col(const float* in_nhwc, int batch, int image, int patch, int channels,
                          void* out16, int dtype, hipStream_t stream);

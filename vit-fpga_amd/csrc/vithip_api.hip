@@ -189,7 +189,7 @@ struct vh_ctx {
     bool guard_auto = false, guard_tripped = false;
     // activations (sized for max_batch)
     char* arena = nullptr;
-    unsigned int* tickets = nullptr;   // [max_batch] work-queue counters of the attention kernel (launch_attention)
+    unsigned int* tickets = nullptr;   // [max_batch][layers] work-queue counters of the attention kernel (launch_attention)
     float* x = nullptr;       // residual stream [B*T, D] fp32
     void* xn16 = nullptr;     // LN output       [B*T, D]
     void* qkv16 = nullptr;    //                 [B*T, 3D]
@@ -412,6 +412,10 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     char* const h16 = (char*)c->h16 + r0 * M * esz_op;
     char* const col16 = (char*)c->col16 + (size_t)img0 * L.NP * L.KP * esz;
     float* const clsn32 = c->clsn32 + (size_t)img0 * D;
+    // the attention launches' work-queue counters: one word per layer, all zeroed by ONE memset per forward (a memset per
+    // launch is a 5 us fill kernel in front of every attention kernel)
+    unsigned int* const tickets_part = c->tickets + (size_t)img0 * (f.layers > 0 ? f.layers : 1);
+    if (f.layers > 0) HIPCHK(&c->err, hipMemsetAsync(tickets_part, 0, sizeof(unsigned int) * f.layers, s));
     auto mark = [&](int stage) -> int {
         if (!ev) return VH_OK;
         hipEvent_t e;
@@ -489,7 +493,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, c->tickets + img0, s));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, tickets_part + l, s, true));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
@@ -583,7 +587,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, op_dt, c->tickets + img0, s));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, op_dt, tickets_part + l, s, true));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = resid_gemm_ln(att16, c->wo16[l], P + o.ob, so, D, P + o.ln2w, P + o.ln2b, ST_PROJ))) return rc;
@@ -888,7 +892,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
                  o_cls = carve(B * D * 4),
                  o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4),
                  o_st = carve(rows_p * 2 * 4), o_pt = carve((D / 64 + 1) * rows_p * 2 * 4), o_xlo = carve(rows_p * D * 2),
-                 o_tk = carve(B * 4),   // attention work-queue counters: one word per image, a part uses its first image's
+                 o_tk = carve(B * 4 * (size_t)(cfg->layers > 0 ? cfg->layers : 1)),   // attention work-queue counters: one word per image and layer, a part uses its first image's
                  o_gd = carve(256);     // the LayerNorm-fold guard word
     CK(hipMalloc((void**)&c->arena, a));
     c->guard_dev = (unsigned int*)(c->arena + o_gd);
