@@ -250,9 +250,10 @@ int vh_debug_set_layers(vh_ctx* ctx, int n_layers);
 #define VH_EPI_LNFOLD 5      /* out16[m,n]  = rstd[m]*(acc - mean[m]*c[n]) + d[n]   (LayerNorm folded: bias = d, aux = c) */
 #define VH_EPI_LNFOLD_GELU 6 /* gelu of the above                                          */
 #define VH_EPI_RESID_LN 7    /* out32 += acc + bias; out16 = 16-bit copy; partials[N/64][M][2] = row (sum, sumsq) */
-#define VH_EPI_RESID_SPLIT 8 /* residual kept as TWO 16-bit planes, x = hi + lo: (hi, lo) += acc + bias with hi = T(x), lo = T(x - hi);
-                                out = hi plane (the next GEMM's A operand), out16 = lo plane, partials as RESID_LN.  4 B per
-                                element each way instead of 4 B + the 2 B copy of RESID_LN */
+#define VH_EPI_RESID_SPLIT 8 /* residual kept as TWO planes, x = hi + lo: (hi, lo) += acc + bias with hi = T(x) (16 bit) and lo = what that
+                                rounding dropped, ONE byte per element: e4m3((x - hi) * 128) for bf16, * 1024 for fp16 (12 / 15
+                                significant bits of x in the pair).  out = hi plane (the next GEMM's A operand), out16 = lo plane
+                                [M,N] bytes, partials as RESID_LN.  3 B per element each way instead of 4 B + the 2 B copy of RESID_LN */
 #define VH_EPI_PATCH_SPLIT 9 /* the patch embedding written directly as the split residual: row(m) of (hi, lo) = the planes of
                                 acc + bias + pos[tok(m)], plus that row's partial sums (partials[N/64][R][2], R = token rows) --
                                 EPI_PATCH and the first row-statistics pass in one epilogue.  out = hi, out16 = lo, aux /
@@ -286,7 +287,8 @@ int vh_op_rowstats_cast(const float* x_dev, int64_t rows, int dim, float eps, vo
                         int dtype, void* stream);
 int vh_op_finalize_stats(const float* partials_dev, int nblk, int64_t rows, int dim, float eps, float* stats_dev,
                          void* stream);
-/* x fp32 [rows, dim] -> the two 16-bit planes of the split residual (hi = T(x), lo = T(x - hi)) and stats [rows][2] */
+/* x fp32 [rows, dim] -> the two planes of the split residual (hi = T(x), 16 bit; lo = one scaled e4m3 byte per element, see
+ * VH_EPI_RESID_SPLIT) and stats [rows][2] */
 int vh_op_rowstats_split(const float* x_dev, int64_t rows, int dim, float eps, void* hi_dev, void* lo_dev, float* stats_dev,
                          int dtype, void* stream);
 /* W'[n,k] = dtype(scale * gamma[k] * W[n,k]); c[n] = sum_k W'[n,k]; d[n] = scale * (sum_k beta[k] W[n,k] + b[n]) */

@@ -423,33 +423,36 @@ def test_gemm_resid_ln_epilogue(dt, variant):
 @pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_resid_split_epilogue(dt, variant):
-    """The residual stream as two 16-bit planes, x = hi + lo (VH_EPI_RESID_SPLIT): (hi, lo) += A W^T + bias.  Checked against
-    the oracle's fp32 update of the SAME starting value hi0 + lo0: the new hi is the 16-bit rounding of the new x, hi + lo
-    reproduces it to the planes' joint precision (2^-16 for bf16, 2^-21 for fp16, of the row's scale), the per-64-column
-    row sums are those of the new x, rows outside M are untouched (ragged M, canary rows)."""
+    """The residual stream as two planes, x = hi + lo (VH_EPI_RESID_SPLIT): hi = T(x), 16 bit, the next GEMM's operand; lo = what
+    that rounding dropped, one scaled e4m3 byte.  (hi, lo) += A W^T + bias, checked against the oracle's fp32 update of the SAME
+    starting value hi0 + lo0: the new hi is the 16-bit rounding of the new x, hi + lo reproduces it to the planes' joint
+    precision (lo's own rounding: 2^-4 of half an ulp of hi, i.e. 12 / 15 significant bits), the per-64-column row sums are
+    those of the new x (taken before lo is rounded), rows outside M are untouched (ragged M, canary rows)."""
     M, N, K = 700, 512, 192
     a = rnd16(S.fill(M * K, 29, 1, 0).reshape(M, K), dt)
     w = rnd16(S.fill(N * K, 29, 2, 1, 0.1).reshape(N, K), dt)
     bias = S.fill(N, 29, 3, 1, 0.1)
     x0 = (S.fill((M + 2) * N, 29, 4, 0) * 3.0).reshape(M + 2, N)
     hi0 = rnd16(x0, dt)
-    lo0 = rnd16(x0 - hi0, dt)
+    lo0_8 = vithip.to_lo8(x0 - hi0, dt)
+    lo0 = vithip.from_lo8(lo0_8, dt)
     ref = (hi0 + lo0)[1:-1] + O.linear(a, w, bias)
-    hi, lo = dev(vithip.to16(hi0, dt)), dev(vithip.to16(lo0, dt))
+    hi, lo = dev(vithip.to16(hi0, dt)), dev(lo0_8)
     parts = vithip.DeviceBuffer((N // 64) * M * 8)
     vithip.op_gemm_ex(dev(vithip.to16(a, dt)).ptr, dev(vithip.to16(w, dt)).ptr, dev(bias).ptr, hi.ptr + N * 2, M, N, K,
-                      vithip.EPI_RESID_SPLIT, dt, out16_ptr=lo.ptr + N * 2, partials_ptr=parts.ptr, variant=variant)
+                      vithip.EPI_RESID_SPLIT, dt, out16_ptr=lo.ptr + N, partials_ptr=parts.ptr, variant=variant)
     h = vithip.from16(hi.to_numpy(np.uint16, (M + 2, N)), dt)
-    l = vithip.from16(lo.to_numpy(np.uint16, (M + 2, N)), dt)
+    l = vithip.from_lo8(lo.to_numpy(np.uint8, (M + 2, N)), dt)
     for plane, before in ((h, hi0), (l, lo0)):
         assert np.array_equal(plane[0], before[0]) and np.array_equal(plane[-1], before[-1])   # canary rows
     got = h[1:-1].astype(np.float64) + l[1:-1]
     scale = np.abs(ref).max()
-    assert np.abs(got - ref).max() <= (2.0 ** -15 if dt == vithip.DTYPE_BF16 else 2.0 ** -20) * scale + 2e-5 * scale
+    # lo is a 4-bit-significand rounding of a residue of at most half an ulp of hi (+ the byte's underflow step)
+    assert (np.abs(got - ref) <= ULP[dt] * np.abs(ref) * 2.0 ** -4 * 1.05 + 2.0 ** -10 / vithip.LO8_SCALE[dt] + 2e-5 * scale).all()
     # hi is the 16-bit rounding of the updated value (up to the last-bit effect of the GEMM's summation order)
     assert (np.abs(h[1:-1] - ref) <= ULP[dt] * np.abs(ref) * 1.01 + 2e-5 * scale).all()
     p = parts.to_numpy(np.float32, (N // 64, M, 2))
-    g64 = got.reshape(M, N // 64, 64)
+    g64 = ref.astype(np.float64).reshape(M, N // 64, 64)      # the statistics are those of the updated x BEFORE its planes are rounded
     assert np.abs(p[:, :, 0].T - g64.sum(2)).max() <= 2e-4 * scale
     assert np.abs(p[:, :, 1].T - (g64 ** 2).sum(2)).max() <= 1e-4 * (g64 ** 2).sum(2).max()
 
@@ -459,7 +462,7 @@ def test_gemm_resid_split_epilogue(dt, variant):
 @pytest.mark.parametrize("B,NP", [(3, 196), (37, 16), (5, 100)])
 def test_gemm_patch_split_epilogue(dt, variant, B, NP):
     """VH_EPI_PATCH_SPLIT: the patch embedding written directly as the split residual.  Row m = image * NP + p of the GEMM
-    lands on token row image * (NP + 1) + 1 + p as hi = T(x), lo = T(x - hi) of x = A W^T + bias + pos[1 + p], with that
+    lands on token row image * (NP + 1) + 1 + p as hi = T(x), lo = lo8(x - hi) of x = A W^T + bias + pos[1 + p], with that
     row's per-64-column (sum, sum of squares); class-token rows stay untouched (canary).  Patch counts above and below the
     128-row wave tile (one or several image boundaries inside it), ragged M."""
     N, K = 256, 192
@@ -471,7 +474,8 @@ def test_gemm_patch_split_epilogue(dt, variant, B, NP):
     pos = S.fill(T * N, 41, 4, 1, 0.5).reshape(T, N)
     ref = O.linear(a, w, bias).reshape(B, NP, N) + pos[None, 1:, :]
     canary = np.full((B * T, N), 0x3c00 if dt == vithip.DTYPE_FP16 else 0x3f80, dtype=np.uint16)      # 1.0 everywhere
-    hi, lo = dev(canary), dev(canary)
+    canary8 = np.full((B * T, N), 0x38, dtype=np.uint8)                                                # e4m3 1.0
+    hi, lo = dev(canary), dev(canary8)
     parts = vithip.DeviceBuffer((N // 64) * B * T * 8)
     pz = np.full((N // 64, B * T, 2), -7.0, dtype=np.float32)
     vithip.lib().vh_memcpy_h2d(0, parts.ptr, pz.ctypes.data, pz.nbytes)
@@ -479,17 +483,17 @@ def test_gemm_patch_split_epilogue(dt, variant, B, NP):
                       vithip.EPI_PATCH_SPLIT, dt, aux_ptr=dev(pos).ptr, aux_i=NP, out16_ptr=lo.ptr, partials_ptr=parts.ptr,
                       variant=variant)
     h16 = hi.to_numpy(np.uint16, (B, T, N))
-    l16 = lo.to_numpy(np.uint16, (B, T, N))
-    assert (h16[:, 0] == canary[0, 0]).all() and (l16[:, 0] == canary[0, 0]).all()          # class-token rows untouched
-    h, l = vithip.from16(h16, dt)[:, 1:], vithip.from16(l16, dt)[:, 1:]
+    l8 = lo.to_numpy(np.uint8, (B, T, N))
+    assert (h16[:, 0] == canary[0, 0]).all() and (l8[:, 0] == 0x38).all()                   # class-token rows untouched
+    h, l = vithip.from16(h16, dt)[:, 1:], vithip.from_lo8(l8, dt)[:, 1:]
     got = h.astype(np.float64) + l
     scale = np.abs(ref).max()
-    assert np.abs(got - ref).max() <= (2.0 ** -15 if dt == vithip.DTYPE_BF16 else 2.0 ** -20) * scale + 2e-5 * scale
+    assert (np.abs(got - ref) <= ULP[dt] * np.abs(ref) * 2.0 ** -4 * 1.05 + 2.0 ** -10 / vithip.LO8_SCALE[dt] + 2e-5 * scale).all()
     assert (np.abs(h - ref) <= ULP[dt] * np.abs(ref) * 1.01 + 2e-5 * scale).all()
-    assert (np.abs(l) <= ULP[dt] * np.abs(h) * 1.0001 + 1e-30).all()                           # lo is a rounding residue: at most half an ulp of hi
+    assert (np.abs(l) <= ULP[dt] * np.abs(h) * 1.07 + 1e-30).all()                             # lo is a rounding residue: at most half an ulp of hi (+ its own rounding)
     p = parts.to_numpy(np.float32, (N // 64, B, T, 2))
     assert (p[:, :, 0] == -7.0).all()                                                           # no statistics for class-token rows
-    g64 = got.reshape(B, NP, N // 64, 64)
+    g64 = ref.astype(np.float64).reshape(B, NP, N // 64, 64)   # statistics of x before its planes are rounded
     assert np.abs(np.moveaxis(p[:, :, 1:, 0], 0, 2) - g64.sum(3)).max() <= 2e-4 * scale
     assert np.abs(np.moveaxis(p[:, :, 1:, 1], 0, 2) - (g64 ** 2).sum(3)).max() <= 1e-4 * (g64 ** 2).sum(3).max()
 
@@ -498,12 +502,12 @@ def test_rowstats_split_planes_and_statistics():
     for dt in DT:
         rows, dim = 333, 768
         x = (S.fill(rows * dim, 31, 5, 0) * 2.0 + 0.3).reshape(rows, dim)
-        hi, lo, st = vithip.DeviceBuffer(rows * dim * 2), vithip.DeviceBuffer(rows * dim * 2), vithip.DeviceBuffer(rows * 8)
+        hi, lo, st = vithip.DeviceBuffer(rows * dim * 2), vithip.DeviceBuffer(rows * dim), vithip.DeviceBuffer(rows * 8)
         vithip.op_rowstats_split(dev(x).ptr, rows, dim, 1e-6, hi.ptr, lo.ptr, st.ptr, dt)
         h16 = hi.to_numpy(np.uint16, (rows, dim))
         assert np.array_equal(h16, vithip.to16(x, dt))
         h = vithip.from16(h16, dt)
-        assert np.array_equal(lo.to_numpy(np.uint16, (rows, dim)), vithip.to16(x - h, dt))
+        assert np.array_equal(lo.to_numpy(np.uint8, (rows, dim)), vithip.to_lo8(x - h, dt))
         s = st.to_numpy(np.float32, (rows, 2))
         x64 = x.astype(np.float64)
         assert np.abs(s[:, 0] - x64.mean(1)).max() <= 1e-6
@@ -533,16 +537,16 @@ def test_gemm_persistent_walks_several_tiles_per_workgroup(dt, epi):
         for variant in (5, 6):
             out = vithip.DeviceBuffer(M * N * 2)
             if epi in ("resid_ln", "resid_split"):
-                # residual read-modify-write (fp32 + 16-bit copy, or the two 16-bit planes) + per-64-column row sums: every
+                # residual read-modify-write (fp32 + 16-bit copy, or the 16-bit + one-byte planes) + per-64-column row sums: every
                 # output must be identical
                 split = epi == "resid_split"
                 xb = vithip.DeviceBuffer.from_numpy(vithip.to16(x0, dt) if split else x0)
-                o16 = vithip.DeviceBuffer.from_numpy(vithip.to16(x0 - vithip.from16(vithip.to16(x0, dt), dt), dt)) if split \
+                o16 = vithip.DeviceBuffer.from_numpy(vithip.to_lo8(x0 - vithip.from16(vithip.to16(x0, dt), dt), dt)) if split \
                     else vithip.DeviceBuffer(M * N * 2)
                 parts = vithip.DeviceBuffer((N // 64) * M * 2 * 4)
                 vithip.op_gemm_ex(A.ptr, W.ptr, Bv.ptr, xb.ptr, M, N, K, vithip.EPI_RESID_SPLIT if split else vithip.EPI_RESID_LN, dt,
                                   out16_ptr=o16.ptr, partials_ptr=parts.ptr, variant=variant)
-                outs.append(np.concatenate([xb.to_numpy(np.uint16, (M * N * (1 if split else 2),)), o16.to_numpy(np.uint16, (M * N,)),
+                outs.append(np.concatenate([xb.to_numpy(np.uint16, (M * N * (1 if split else 2),)), o16.to_numpy(np.uint16, (M * N // (2 if split else 1),)),
                                             parts.to_numpy(np.uint16, ((N // 64) * M * 4,))]))
                 xb.free(); o16.free(); parts.free(); out.free()
                 continue

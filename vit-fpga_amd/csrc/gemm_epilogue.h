@@ -273,7 +273,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
         }
     } else if constexpr (EPI == VH_EPI_RESID_SPLIT || EPI == VH_EPI_PATCH_SPLIT) {
         // split residual: stage acc + bias as fp32 rows (256 B, chunk ^ (r & 15)) like the fp32 form, read back EIGHT columns per
-        // lane (two chunks), so that the hi and the lo plane are each accessed 16 B per lane / 128 B per row.  What the row
+        // lane (two chunks): the hi plane is accessed 16 B per lane / 128 B per row, the one-byte lo plane 8 B per lane / 64 B per row.  What the row
         // ADDS -- its own planes (RESID_SPLIT) or the position embedding's fp32 row (PATCH_SPLIT: the patch embedding lands
         // directly in the split form, on the remapped row m + m / patches + 1, with the first row statistics) -- is loaded for
         // pass h+1 before pass h is processed (same reason as in the fp32 form below).
@@ -282,10 +282,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
         constexpr int FMI = SMI / 2, NP = MI / FMI, NL = FMI * 2;
         const int rr = lane >> 3, pc = lane & 7;
         elem* const hi = (elem*)e.out;
-        elem* const lo = (elem*)e.out16;
+        uint8_t* const lo = (uint8_t*)e.out16;   // one e4m3 byte per element (Lo8<T>, vh_common.h)
         const int64_t prow = PATCHS ? e.prow : (int64_t)M;
         // 8 fp32 addends per lane and line: RESID_SPLIT converts its two 16-bit planes on use, PATCH_SPLIT loads them as is
-        struct Add { vec8 h, l; f32x4 p0, p1; };
+        struct Add { vec8 h; u32x2 l; f32x4 p0, p1; };
         Add xa[2][NL];
         // PATCH_SPLIT: GEMM row m = image * patches + p lands on token row m + image + 1 and adds pos row 1 + p.  One scalar
         // division per wave tile (m_w is wave-uniform), then a carry per row instead of a vector division per line.
@@ -315,8 +315,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                     a[i].p0 = *(const f32x4*)pr;
                     a[i].p1 = *(const f32x4*)(pr + 4);
                 } else {
-                    if (m < M && !(VH_EPI_ABL & 8)) { a[i].h = *(const vec8*)(hi + off); a[i].l = *(const vec8*)(lo + off); }
-                    else { a[i].h = vec8{}; a[i].l = vec8{}; }
+                    if (m < M && !(VH_EPI_ABL & 8)) { a[i].h = *(const vec8*)(hi + off); a[i].l = *(const u32x2*)(lo + off); }
+                    else { a[i].h = vec8{}; a[i].l = u32x2{0u, 0u}; }
                 }
             }
         };
@@ -341,20 +341,25 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 const int64_t off = where(h, i, m, orow, p);
                 const bool ok = m < M;
                 const Add& a = xa[h & 1][i];
-                float v[8];
-                vec8 hn, ln;
+                float v[8], ln[8];
+                vec8 hn;
                 float s1 = 0.f, s2 = 0.f;
+                f32x4 l0 = f32x4{0.f, 0.f, 0.f, 0.f}, l1 = l0;
+                if constexpr (!PATCHS) { l0 = lo8_unpack4<T>(a.l[0]); l1 = lo8_unpack4<T>(a.l[1]); }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    // RESID_SPLIT: hi + lo is exact in fp32 (at most 17 / 23 significant bits), then ONE rounding of the sum with the update
-                    const float add = PATCHS ? (j < 4 ? a.p0[j] : a.p1[j - 4]) : ((float)a.h[j] + (float)a.l[j]);
+                    // RESID_SPLIT: x = hi + lo (exact in fp32 up to its 24 bits), then ONE rounding of the sum with the update
+                    const float add = PATCHS ? (j < 4 ? a.p0[j] : a.p1[j - 4]) : ((float)a.h[j] + (j < 4 ? l0[j] : l1[j - 4]));
                     v[j] = (j < 4 ? v0[j] : v1[j - 4]) + add;
                     hn[j] = (elem)v[j];
-                    ln[j] = (elem)(v[j] - (float)hn[j]);
+                    ln[j] = v[j] - (float)hn[j];
                     s1 += v[j];
                     s2 = fmaf(v[j], v[j], s2);
                 }
-                if (ok && !(VH_EPI_ABL & 4)) { *(vec8*)(hi + off) = hn; *(vec8*)(lo + off) = ln; }
+                if (ok && !(VH_EPI_ABL & 4)) {
+                    *(vec8*)(hi + off) = hn;
+                    *(u32x2*)(lo + off) = u32x2{lo8_pack4<T>(ln[0], ln[1], ln[2], ln[3]), lo8_pack4<T>(ln[4], ln[5], ln[6], ln[7])};
+                }
                 // the 8 lanes of a row: quad butterflies, then the mirrored half-row (lane i <-> 7 - i) joins the two quads
                 s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);     // quad_perm [1,0,3,2]
                 s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);     // quad_perm [2,3,0,1]

@@ -133,7 +133,7 @@ hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int bat
 // per image; a lane owns column 64 * blk + lane of every block; fixed-order butterfly sums.
 template <typename T>
 __global__ void __launch_bounds__(256)
-cls_rows_split_kernel(typename T::elem* __restrict__ hi, typename T::elem* __restrict__ lo, float* __restrict__ partials, int64_t prow,
+cls_rows_split_kernel(typename T::elem* __restrict__ hi, uint8_t* __restrict__ lo, float* __restrict__ partials, int64_t prow,
                       const float* __restrict__ cls, const float* __restrict__ pos, int batch, int tokens, int dim) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -146,7 +146,7 @@ cls_rows_split_kernel(typename T::elem* __restrict__ hi, typename T::elem* __res
             v = cls[d] + pos[d];
             const typename T::elem h = (typename T::elem)v;
             hi[row * dim + d] = h;
-            lo[row * dim + d] = (typename T::elem)(v - (float)h);
+            lo[row * dim + d] = lo8_pack1<T>(v - (float)h);
         }
         float s1 = v, s2 = v * v;
 #pragma unroll
@@ -159,9 +159,9 @@ hipError_t launch_cls_rows_split(void* hi, void* lo, float* partials, int64_t pr
     if (batch <= 0 || dim % 64) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((batch + 3) / 4));
     if (dtype == VH_DTYPE_BF16)
-        hipLaunchKernelGGL(cls_rows_split_kernel<BF16>, grid, dim3(256), 0, s, (BF16::elem*)hi, (BF16::elem*)lo, partials, prow, cls, pos, batch, tokens, dim);
+        hipLaunchKernelGGL(cls_rows_split_kernel<BF16>, grid, dim3(256), 0, s, (BF16::elem*)hi, (uint8_t*)lo, partials, prow, cls, pos, batch, tokens, dim);
     else
-        hipLaunchKernelGGL(cls_rows_split_kernel<FP16>, grid, dim3(256), 0, s, (FP16::elem*)hi, (FP16::elem*)lo, partials, prow, cls, pos, batch, tokens, dim);
+        hipLaunchKernelGGL(cls_rows_split_kernel<FP16>, grid, dim3(256), 0, s, (FP16::elem*)hi, (uint8_t*)lo, partials, prow, cls, pos, batch, tokens, dim);
     return hipGetLastError();
 }
 
@@ -441,7 +441,7 @@ hipError_t launch_mlp_update(float* w, float* b, const float* d, const float* x,
 template <typename T, int CH>
 __global__ void __launch_bounds__(256)
 rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float eps, typename T::elem* __restrict__ x16,
-                     float* __restrict__ stats, typename T::elem* __restrict__ xlo) {   // xlo != NULL: the split residual's lo plane
+                     float* __restrict__ stats, uint8_t* __restrict__ xlo) {   // xlo != NULL: the split residual's lo plane (one byte per element)
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -468,8 +468,8 @@ rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float e
             const typename T::vec4 hq = pack4<T>(v[i][0], v[i][1], v[i][2], v[i][3]);
             *(typename T::vec4*)(x16 + row * dim + 4 * c) = hq;
             if constexpr (!std::is_same<T, E4M3>::value) {
-                if (xlo) *(typename T::vec4*)(xlo + row * dim + 4 * c) = pack4<T>(v[i][0] - (float)hq[0], v[i][1] - (float)hq[1],
-                                                                               v[i][2] - (float)hq[2], v[i][3] - (float)hq[3]);
+                if (xlo) *(uint32_t*)(xlo + row * dim + 4 * c) = lo8_pack4<T>(v[i][0] - (float)hq[0], v[i][1] - (float)hq[1],
+                                                                            v[i][2] - (float)hq[2], v[i][3] - (float)hq[3]);
             }
         }
     }
@@ -482,7 +482,7 @@ template <typename T>
 static hipError_t rowstats_t(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, hipStream_t s, void* xlo = nullptr) {
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     auto o = (typename T::elem*)x16;
-    auto lo = (typename T::elem*)xlo;
+    auto lo = (uint8_t*)xlo;
     if (dim <= 256) hipLaunchKernelGGL((rowstats_cast_kernel<T, 1>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
     else if (dim <= 512) hipLaunchKernelGGL((rowstats_cast_kernel<T, 2>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
     else if (dim <= 768) hipLaunchKernelGGL((rowstats_cast_kernel<T, 3>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
@@ -506,38 +506,38 @@ hipError_t launch_rowstats_split(const float* x, int64_t rows, int dim, float ep
                                   : rowstats_t<FP16>(x, rows, dim, eps, hi, stats, s, lo);
 }
 
-// LayerNorm of selected rows of the SPLIT residual (x = hi + lo, two 16-bit planes) -> fp32: the final LayerNorm of the
+// LayerNorm of selected rows of the SPLIT residual (x = hi + lo: a 16-bit plane and a one-byte plane, Lo8<T>) -> fp32: the final LayerNorm of the
 // CLS rows in front of the fp32 head.  One wave per row, two-pass statistics like layernorm_kernel.
 template <typename T>
 __global__ void __launch_bounds__(256)
-layernorm_split_kernel(const typename T::elem* __restrict__ hi, const typename T::elem* __restrict__ lo, int64_t rows, int dim,
+layernorm_split_kernel(const typename T::elem* __restrict__ hi, const uint8_t* __restrict__ lo, int64_t rows, int dim,
                        int64_t row_stride, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                        float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const typename T::elem* hr = hi + row * row_stride;
-    const typename T::elem* lr = lo + row * row_stride;
+    const uint8_t* lr = lo + row * row_stride;
     float sum = 0.f;
-    for (int k = lane; k < dim; k += 64) sum += (float)hr[k] + (float)lr[k];
+    for (int k = lane; k < dim; k += 64) sum += (float)hr[k] + lo8_unpack1<T>(lr[k]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum / (float)dim;
     float var = 0.f;
-    for (int k = lane; k < dim; k += 64) { const float d = ((float)hr[k] + (float)lr[k]) - mean; var += d * d; }
+    for (int k = lane; k < dim; k += 64) { const float d = ((float)hr[k] + lo8_unpack1<T>(lr[k])) - mean; var += d * d; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
     const float rstd = 1.0f / sqrtf(var / (float)dim + eps);
-    for (int k = lane; k < dim; k += 64) out[row * dim + k] = (((float)hr[k] + (float)lr[k]) - mean) * rstd * gamma[k] + beta[k];
+    for (int k = lane; k < dim; k += 64) out[row * dim + k] = (((float)hr[k] + lo8_unpack1<T>(lr[k])) - mean) * rstd * gamma[k] + beta[k];
 }
 hipError_t launch_layernorm_split(const void* hi, const void* lo, int64_t rows, int dim, int64_t row_stride, const float* gamma,
                                   const float* beta, float eps, float* out32, int dtype, hipStream_t s) {
     if (rows <= 0 || dim <= 0) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (dtype == VH_DTYPE_BF16)
-        hipLaunchKernelGGL(layernorm_split_kernel<BF16>, grid, block, 0, s, (const BF16::elem*)hi, (const BF16::elem*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
+        hipLaunchKernelGGL(layernorm_split_kernel<BF16>, grid, block, 0, s, (const BF16::elem*)hi, (const uint8_t*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
     else
-        hipLaunchKernelGGL(layernorm_split_kernel<FP16>, grid, block, 0, s, (const FP16::elem*)hi, (const FP16::elem*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
+        hipLaunchKernelGGL(layernorm_split_kernel<FP16>, grid, block, 0, s, (const FP16::elem*)hi, (const uint8_t*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
     return hipGetLastError();
 }
 

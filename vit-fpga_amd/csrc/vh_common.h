@@ -97,6 +97,33 @@ __device__ __forceinline__ f32x4 pack4<F32OUT>(float a, float b, float c, float 
     return f32x4{a, b, c, d};
 }
 
+// ---- lo plane of the split residual (x = hi + lo): ONE e4m3 byte per element ----------------------------
+// hi = T(x) is the next GEMM's operand; lo carries what that rounding dropped.  |x - hi| <= |x| * 2^-8 (bf16) / 2^-11
+// (fp16), so lo is stored SCALED by 128 / 1024: the byte then holds a value of at most |x| / 2 (saturating beyond |x| =
+// 896), and e4m3's 4 significant bits put the pair at 12 (bf16) / 15 (fp16) significant bits of x -- the rounding a
+// residual update injects, 2^-13 / 2^-16 relative, is 16x below the 2^-9 / 2^-12 the operand rounding of every GEMM input
+// injects anyway -- for 6 instead of 8 bytes per element and update.  Powers of two: scaling is exact.
+template <typename T> struct Lo8;
+template <> struct Lo8<BF16> { static constexpr float scale = 128.f, inv = 1.f / 128.f; };
+template <> struct Lo8<FP16> { static constexpr float scale = 1024.f, inv = 1.f / 1024.f; };
+template <typename T>
+__device__ __forceinline__ uint32_t lo8_pack4(float a, float b, float c, float d) {   // the four residues x - hi
+    return pack4_e4m3(a * Lo8<T>::scale, b * Lo8<T>::scale, c * Lo8<T>::scale, d * Lo8<T>::scale);
+}
+template <typename T>
+__device__ __forceinline__ f32x4 lo8_unpack4(uint32_t w) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+    return f32x4{a[0] * Lo8<T>::inv, a[1] * Lo8<T>::inv, b[0] * Lo8<T>::inv, b[1] * Lo8<T>::inv};
+}
+template <typename T>
+__device__ __forceinline__ uint8_t lo8_pack1(float a) {
+    a = __builtin_amdgcn_fmed3f(a * Lo8<T>::scale, -448.f, 448.f);
+    return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(a, a, 0, false) & 0xFF);
+}
+template <typename T>
+__device__ __forceinline__ float lo8_unpack1(uint8_t b) { return __builtin_amdgcn_cvt_f32_fp8((int)b, 0) * Lo8<T>::inv; }
+
 // ---- inline-asm vector-memory instructions with scalar operands: ONE place for the hazard rule --------------------------
 // hipcc's hazard recogniser does not look into an asm string.  A scalar operand ("s") of a VMEM instruction inside one may
 // have been written by a VALU instruction immediately in front of the statement -- v_readlane / v_readfirstlane when the

@@ -170,11 +170,12 @@ struct vh_ctx {
     float* fold_cd = nullptr; // per layer: cqkv[3D] dqkv[3D] c1[M] d1[M]
     float* stats = nullptr;   // [B*T][2] (mean, rstd) of the current residual rows
     float* partials = nullptr;// [D/64][B*T][2]
-    // with the fold: the residual stream lives as two 16-bit planes, x = hi + lo (hi = the xn16 buffer = the GEMMs' A operand,
-    // lo = xlo16): a residual GEMM then moves 4 B per element each way instead of the fp32 array plus its 16-bit copy.
+    // with the fold: the residual stream lives as two planes, x = hi + lo (hi = the xn16 buffer = the GEMMs' 16-bit A operand,
+    // lo = xlo16 = what that rounding dropped, one scaled e4m3 byte per element: vh_common.h Lo8): a residual GEMM then moves
+    // 3 B per element each way instead of the fp32 array plus its 16-bit copy.
     // VH_RESID_SPLIT=0 (A/B tools) keeps the fp32 array.
     bool split = false;
-    void* xlo16 = nullptr;    // [B*T, D]
+    void* xlo16 = nullptr;    // [B*T, D] bytes
     // Run-time guard on the fold: the kernels that produce the row statistics keep a running maximum of
     // |mean| * rstd over the REAL rows (guard_dev: the bits of a non-negative float); every forward ends with an
     // asynchronous copy of that word into pinned host memory, and every forward entry point looks at the copy before it
@@ -406,7 +407,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     float* const stats_p = c->stats + r0 * 2;
     float* const partials_p = c->partials + (size_t)(D / 64) * r0 * 2;
     char* const xn16 = (char*)c->xn16 + r0 * D * esz_op;
-    char* const xlo16 = (char*)c->xlo16 + r0 * D * esz;
+    char* const xlo16 = (char*)c->xlo16 + r0 * D;   // the lo plane: one byte per element
     char* const qkv16 = (char*)c->qkv16 + r0 * 3 * D * esz;
     char* const att16 = (char*)c->att16 + r0 * D * esz_op;
     char* const h16 = (char*)c->h16 + r0 * M * esz_op;
@@ -891,7 +892,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
                  o_att = carve(rows_p * D * 2), o_h = carve(rows_p * M * 2), o_col = carve(B * L.NP * (size_t)L.KP * 2),
                  o_cls = carve(B * D * 4),
                  o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4),
-                 o_st = carve(rows_p * 2 * 4), o_pt = carve((D / 64 + 1) * rows_p * 2 * 4), o_xlo = carve(rows_p * D * 2),
+                 o_st = carve(rows_p * 2 * 4), o_pt = carve((D / 64 + 1) * rows_p * 2 * 4), o_xlo = carve(rows_p * D),
                  o_tk = carve(B * 4 * (size_t)(cfg->layers > 0 ? cfg->layers : 1)),   // attention work-queue counters: one word per image and layer, a part uses its first image's
                  o_gd = carve(256);     // the LayerNorm-fold guard word
     CK(hipMalloc((void**)&c->arena, a));
@@ -1472,15 +1473,22 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
         const size_t n = (size_t)c->last_batch * c->L.T * D;
         if (n_floats != n) return fail(&c->err, VH_ERR_INVALID, "expected %zu floats", n);
         const int nl = (c->run_layers < 0 || c->run_layers > c->cfg.layers) ? c->cfg.layers : c->run_layers;
-        if (c->split && nl > 0) {   // the residual stream lives as two 16-bit planes: x = hi + lo
-            std::vector<uint16_t> hi(n), lo(n);
+        if (c->split && nl > 0) {   // the residual stream lives as two planes: x = hi (16 bit) + lo (one scaled e4m3 byte)
+            std::vector<uint16_t> hi(n);
+            std::vector<uint8_t> lo(n);
             HIPCHK(&c->err, hipMemcpy(hi.data(), c->xn16, n * 2, hipMemcpyDeviceToHost));
-            HIPCHK(&c->err, hipMemcpy(lo.data(), c->xlo16, n * 2, hipMemcpyDeviceToHost));
+            HIPCHK(&c->err, hipMemcpy(lo.data(), c->xlo16, n, hipMemcpyDeviceToHost));
             auto f = [&](uint16_t b) {
                 if (c->dt16 == VH_DTYPE_BF16) { uint32_t u = (uint32_t)b << 16; float v; memcpy(&v, &u, 4); return v; }
                 _Float16 hv; memcpy(&hv, &b, 2); return (float)hv;
             };
-            for (size_t i = 0; i < n; ++i) host_out[i] = f(hi[i]) + f(lo[i]);
+            auto g = [&](uint8_t b) {   // OCP e4m3fn -> float, then the plane's scale (vh_common.h Lo8<T>)
+                const int e = (b >> 3) & 15, m = b & 7;
+                float v = e ? ldexpf(1.f + m / 8.f, e - 7) : ldexpf(m / 8.f, -6);
+                if (b & 0x80) v = -v;
+                return v * (c->dt16 == VH_DTYPE_BF16 ? 1.f / 128.f : 1.f / 1024.f);
+            };
+            for (size_t i = 0; i < n; ++i) host_out[i] = f(hi[i]) + g(lo[i]);
             return VH_OK;
         }
         HIPCHK(&c->err, hipMemcpy(host_out, c->x, n * 4, hipMemcpyDeviceToHost));

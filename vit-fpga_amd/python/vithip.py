@@ -603,6 +603,30 @@ def from_e4m3(b):
     return e4m3_table()[np.ascontiguousarray(b, dtype=np.uint8)]
 
 
+def to_e4m3(x):
+    """fp32 -> OCP e4m3fn bytes: round to nearest even, saturating at +-448 (what pack4_e4m3 does on the device)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    pos = e4m3_table()[:127].astype(np.float64)          # codes 0x00 .. 0x7E, ascending (0x7F is NaN)
+    a = np.minimum(np.abs(x).astype(np.float64), 448.0)
+    hi = np.clip(np.searchsorted(pos, a, side="left"), 1, 126)
+    lo = hi - 1
+    dl, dh = a - pos[lo], pos[hi] - a
+    code = np.where(dl < dh, lo, np.where(dh < dl, hi, np.where(lo % 2 == 0, lo, hi)))
+    return (code | np.where(np.signbit(x), 0x80, 0)).astype(np.uint8)
+
+
+# ---- the lo plane of the split residual: one e4m3 byte per element, scaled (csrc/vh_common.h Lo8) ----
+LO8_SCALE = {DTYPE_BF16: 128.0, DTYPE_FP16: 1024.0}
+
+
+def to_lo8(residue, dtype):
+    return to_e4m3(np.asarray(residue, dtype=np.float32) * np.float32(LO8_SCALE[dtype]))
+
+
+def from_lo8(b, dtype):
+    return from_e4m3(b) / np.float32(LO8_SCALE[dtype])
+
+
 def op_gemm_ex(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, dtype, aux_ptr=None, aux_i=0, stats_ptr=None,
                out16_ptr=None, partials_ptr=None, variant=0):
     _check(lib().vh_op_gemm_ex(a_ptr, w_ptr, bias_ptr, out_ptr, M, N, K, epilogue, aux_ptr, aux_i, stats_ptr, out16_ptr,
