@@ -270,6 +270,15 @@ int vh_op_gemm(const void* a16_dev, const void* w16_dev, const float* bias_dev, 
  * (saturating), VH_EPI_BIAS_RESID (out += ...) / VH_EPI_BIAS_F32 -> fp32.  K % 128 == 0, N % 4 == 0. */
 int vh_op_gemm_fp8(const void* a8, const void* w8, const float* w_scale, const float* bias, void* out, int64_t M,
                    int N, int K, int epilogue, int variant /* 0 auto, 5, 7 */, void* stream);
+/* the same kernel with the epilogues of the folded-LayerNorm layer loop of the fp8 path (operator tests):
+ *   VH_EPI_LNFOLD / VH_EPI_LNFOLD_GELU  out (bf16 / e4m3) = [gelu](rstd[m] * (w_scale[n] * acc - mean[m] * c[n]) + bias[n]);
+ *                                       c_dev [N], stats_dev [M][2] = (mean, rstd); N % 256 == 0 for the GELU form
+ *   VH_EPI_RESID_LN     out fp32 [M,N] += w_scale * acc + bias; out16 = its e4m3 copy; partials [N/64][M][2]
+ *   VH_EPI_RESID_SPLIT  the residual kept as an e4m3 plane (out: hi = e4m3(x), the next GEMM's operand) and a bf16 plane
+ *                       (out16: lo = bf16(x - hi)): (hi, lo) += w_scale * acc + bias; partials as above.  N % 256 == 0 */
+int vh_op_gemm_fp8_ex(const void* a8, const void* w8, const float* w_scale, const float* bias, void* out, int64_t M,
+                      int N, int K, int epilogue, const float* c_dev, const float* stats_dev, void* out16,
+                      float* partials, int variant, void* stream);
 /* the load-time weight quantiser: s0 = amax(row)/448 (1 for an all-zero row), w8 = rne_e4m3(w / s0),
  * scale[row] = s0 * post_scale */
 int vh_op_quantize_rows(const float* w, int rows, int cols, float post_scale, void* w8, float* scale, void* stream);

@@ -324,3 +324,67 @@ def test_gemm_persistent_form_equals_one_tile_per_workgroup_form(epi):
             outs.append(out.to_numpy(np.uint8, (nbytes,)).copy())
             out.free()
         assert np.array_equal(outs[0], outs[1]), f"{(outs[0] != outs[1]).sum()} bytes differ ({M}x{N}x{K})"
+
+
+@pytest.mark.parametrize("variant", [5, 6])
+def test_gemm_folded_layer_epilogues_on_e4m3_operands(variant):
+    """The epilogues of the fp8 path's folded-LayerNorm layer loop, operator by operator (vh_op_gemm_fp8_ex), against fp64
+    arithmetic on the same e4m3 operands: LNFOLD (bf16 out), RESID_LN (fp32 residual + e4m3 copy + partial row sums) and
+    RESID_SPLIT (the residual as an e4m3 plane -- the next GEMM's operand -- plus a bf16 plane: 3 bytes per element)."""
+    M, N, K = 256 * 3 + 57, 512, 256
+    a, a8, w8, wq, sc, bias = _operands(M, N, K, 47)
+    pre = (O.linear(a, wq) * sc[None, :]).astype(np.float64)
+    A, W, SC, Bv = dev(a8), dev(w8), dev(sc), dev(bias)
+    scale = np.abs(pre).max()
+    # ---- LNFOLD: rstd * (s * acc - mean * c) + d
+    st = np.stack([S.fill(M, 48, 1, 1, 0.1), 1.0 + np.abs(S.fill(M, 48, 2, 0))], axis=1).astype(np.float32)
+    cvec = S.fill(N, 48, 3, 1, 0.1)
+    out = vithip.DeviceBuffer(M * N * 2)
+    vithip.op_gemm_fp8_ex(A.ptr, W.ptr, SC.ptr, Bv.ptr, out.ptr, M, N, K, vithip.EPI_LNFOLD, c_ptr=dev(cvec).ptr,
+                          stats_ptr=dev(st).ptr, variant=variant)
+    want = st[:, 1:2] * (pre - st[:, 0:1] * cvec[None, :]) + bias[None, :]
+    got = vithip.from_bf16_bits(out.to_numpy(np.uint16, (M, N)))
+    assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) * 1.01 + 3e-5 * np.abs(want).max())
+    # ---- RESID_LN: fp32 x += ...; e4m3 copy; partial sums
+    x0 = (S.fill((M + 2) * N, 48, 4, 0) * 3.0).reshape(M + 2, N)
+    ref = x0[1:-1].astype(np.float64) + pre + bias[None, :]
+    xb, c8, parts = dev(x0.copy()), vithip.DeviceBuffer(M * N), vithip.DeviceBuffer((N // 64) * M * 8)
+    vithip.op_gemm_fp8_ex(A.ptr, W.ptr, SC.ptr, Bv.ptr, xb.ptr + N * 4, M, N, K, vithip.EPI_RESID_LN, out16_ptr=c8.ptr,
+                          partials_ptr=parts.ptr, variant=variant)
+    x1 = xb.to_numpy(np.float32, (M + 2, N))
+    assert np.array_equal(x1[0], x0[0]) and np.array_equal(x1[-1], x0[-1])
+    assert np.abs(x1[1:-1] - ref).max() <= 3e-5 * max(scale, np.abs(ref).max())
+    g8, w8q = vithip.from_e4m3(c8.to_numpy(np.uint8, (M, N))), O.quant_e4m3(x1[1:-1])
+    assert (g8 == w8q).all()
+    p = parts.to_numpy(np.float32, (N // 64, M, 2))
+    r64 = ref.reshape(M, N // 64, 64)
+    assert np.abs(p[:, :, 0].T - r64.sum(2)).max() <= 2e-4 * np.abs(ref).max()
+    assert np.abs(p[:, :, 1].T - (r64 ** 2).sum(2)).max() <= 1e-4 * (r64 ** 2).sum(2).max()
+    c8.free(); parts.free()
+    # ---- RESID_SPLIT: hi = e4m3(x) (saturating), lo = bf16(x - hi)
+    x0[5, :7] = [600.0, -700.0, 448.0, 449.0, 0.0, 1e-5, -3e-4]          # beyond e4m3's range: lo must carry the rest
+    hi0 = O.quant_e4m3(x0)
+    lo0 = vithip.from_bf16_bits(vithip.to_bf16_bits(x0 - hi0))
+    ref = (hi0 + lo0)[1:-1].astype(np.float64) + pre + bias[None, :]
+    hb, lb = dev(O.e4m3_bytes(x0)), dev(vithip.to_bf16_bits(x0 - hi0))
+    parts = vithip.DeviceBuffer((N // 64) * M * 8)
+    vithip.op_gemm_fp8_ex(A.ptr, W.ptr, SC.ptr, Bv.ptr, hb.ptr + N, M, N, K, vithip.EPI_RESID_SPLIT, out16_ptr=lb.ptr + N * 2,
+                          partials_ptr=parts.ptr, variant=variant)
+    h = vithip.from_e4m3(hb.to_numpy(np.uint8, (M + 2, N)))
+    l = vithip.from_bf16_bits(lb.to_numpy(np.uint16, (M + 2, N)))
+    for plane, before in ((h, hi0), (l, lo0)):
+        assert np.array_equal(plane[0], before[0]) and np.array_equal(plane[-1], before[-1])   # canary rows
+    got = h[1:-1].astype(np.float64) + l[1:-1]
+    big = np.abs(ref).max()
+    # the pair: bf16's half ulp of a residue of at most half an e4m3 step (1/16 of |x|; more where hi saturates)
+    resid = np.maximum(np.abs(ref) * 2.0 ** -4, np.abs(ref) - 448.0)
+    assert (np.abs(got - ref) <= resid * 2.0 ** -8 * 1.05 + 3e-5 * big).all()
+    # hi is the e4m3 rounding of the updated value (up to the last-bit effect of the summation order)
+    want_h = O.quant_e4m3(ref.astype(np.float32))
+    step = np.maximum(np.abs(want_h), 2.0 ** -6) * 2.0 ** -3 + 1e-12
+    assert np.all(np.abs(h[1:-1] - want_h) <= step * 1.001) and (h[1:-1] == want_h).mean() >= 0.995
+    p = parts.to_numpy(np.float32, (N // 64, M, 2))
+    r64 = ref.reshape(M, N // 64, 64)
+    assert np.abs(p[:, :, 0].T - r64.sum(2)).max() <= 2e-4 * big
+    assert np.abs(p[:, :, 1].T - (r64 ** 2).sum(2)).max() <= 1e-4 * (r64 ** 2).sum(2).max()
+    parts.free(); out.free()

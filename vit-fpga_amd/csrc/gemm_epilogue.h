@@ -271,6 +271,77 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 else if (MFULL || m < M) epi_store(v, (u32x4*)((elem*)e.out + (int64_t)m * N + n));
             }
         }
+    } else if constexpr (EPI == VH_EPI_RESID_SPLIT && std::is_same<T, E4M3>::value) {
+        // split residual of the fp8 path: hi = e4m3(x), one byte, which IS the next GEMM's A operand; lo = bf16(x - hi), so the
+        // pair carries 4 + 8 significant bits of x (the same 12 as the bf16 path's planes) in 3 bytes: a residual update
+        // moves 3 B per element each way instead of the fp32 array's 4 B plus the 1 B operand copy of RESID_LN.  Staged and
+        // read back exactly like the 16-bit form below (8 columns per lane: 8 B of hi, 16 B of lo).
+        using lvec8 = typename BF16::vec8;
+        constexpr int FMI = SMI / 2, NP = MI / FMI, NL = FMI * 2;
+        const int rr = lane >> 3, pc = lane & 7;
+        uint8_t* const hi = (uint8_t*)e.out;
+        typename BF16::elem* const lo = (typename BF16::elem*)e.out16;
+        struct Add8 { u32x2 h; lvec8 l; };
+        Add8 xa[2][NL];
+        auto where = [&](int h, int i, int& m) {
+            m = m_w + h * FMI * 16 + i * 8 + rr;
+            return (int64_t)m * N + n_w + 8 * pc;
+        };
+        auto dec4 = [](uint32_t w) {
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            const f32x2_ a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+            return f32x4{a[0], a[1], b[0], b[1]};
+        };
+        auto load_pass = [&](int h, Add8 (&a)[NL]) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                int m;
+                const int64_t off = where(h, i, m);
+                if (m < M && !(VH_EPI_ABL & 8)) { a[i].h = *(const u32x2*)(hi + off); a[i].l = *(const lvec8*)(lo + off); }
+                else { a[i].h = u32x2{0u, 0u}; a[i].l = lvec8{}; }
+            }
+        };
+        load_pass(0, xa[0]);
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            if (h + 1 < NP) load_pass(h + 1, xa[(h + 1) & 1]);
+#pragma unroll
+            for (int mi = 0; mi < FMI; ++mi) {
+                const int r = mi * 16 + frow;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    *(f32x4*)(sw + r * 256 + (((ni * 4 + fq) ^ (r & 15)) << 4)) = acc[h * FMI + mi][ni] + bv[ni];
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int r = i * 8 + rr;
+                const f32x4 v0 = *(const f32x4*)(sw + r * 256 + (((2 * pc) ^ (r & 15)) << 4));
+                const f32x4 v1 = *(const f32x4*)(sw + r * 256 + (((2 * pc + 1) ^ (r & 15)) << 4));
+                int m;
+                const int64_t off = where(h, i, m);
+                const bool ok = m < M;
+                const Add8& a = xa[h & 1][i];
+                const f32x4 h0 = dec4(a.h[0]), h1 = dec4(a.h[1]);
+                float v[8];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = (j < 4 ? v0[j] : v1[j - 4]) + ((j < 4 ? h0[j] : h1[j - 4]) + (float)a.l[j]);
+                    s1 += v[j];
+                    s2 = fmaf(v[j], v[j], s2);
+                }
+                const u32x2 hn{pack4_e4m3(v[0], v[1], v[2], v[3]), pack4_e4m3(v[4], v[5], v[6], v[7])};   // saturating: lo carries what is cut off
+                const f32x4 d0 = dec4(hn[0]), d1 = dec4(hn[1]);
+                lvec8 ln;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ln[j] = (typename BF16::elem)(v[j] - (j < 4 ? d0[j] : d1[j - 4]));
+                if (ok && !(VH_EPI_ABL & 4)) { *(u32x2*)(hi + off) = hn; *(lvec8*)(lo + off) = ln; }
+                s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);     // quad_perm [1,0,3,2]
+                s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);     // quad_perm [2,3,0,1]
+                s1 += dpp_mov<0x141>(s1); s2 += dpp_mov<0x141>(s2);   // row_half_mirror
+                if (ok && pc == 0 && !(VH_EPI_ABL & 1)) *(float2*)(e.partials + 2 * ((int64_t)(n_w >> 6) * M + m)) = make_float2(s1, s2);
+            }
+        }
     } else if constexpr (EPI == VH_EPI_RESID_SPLIT || EPI == VH_EPI_PATCH_SPLIT) {
         // split residual: stage acc + bias as fp32 rows (256 B, chunk ^ (r & 15)) like the fp32 form, read back EIGHT columns per
         // lane (two chunks): the hi plane is accessed 16 B per lane / 128 B per row, the one-byte lo plane 8 B per lane / 64 B per row.  What the row

@@ -450,17 +450,18 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // (fp32 results: 16 rows x 256 B per pass, so that the 8 waves' slices fit the 32 KiB behind the stages)
             constexpr int SLICE = VH_PP_SMI * 16 * 128;
             static_assert(VH_PP_SMI == 2, "staging region of the persistent form: 8 waves x 4 KiB");
-            // fp8 operands: GELU results leave as e4m3 (the next GEMM's A operand); RESID_LN writes an e4m3 copy of the rows
+            // fp8 operands: GELU results leave as e4m3 (the next GEMM's A operand); RESID_LN writes an e4m3 copy of the rows, RESID_SPLIT
+            // keeps the residual itself as an e4m3 plane (that operand) + a bf16 plane
             if constexpr (F8 && epi_has_gelu(EPI))
                 gemm_epilogue8<EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, true, stage_epi, wave);
-            else if constexpr (F8 && EPI == VH_EPI_RESID_LN)
+            else if constexpr (F8 && (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT))
                 gemm_epilogue_staged<E4M3, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
             else
                 gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
         } else {
             if constexpr (F8 && epi_has_gelu(EPI))
                 gemm_epilogue8<EPI, MI, NI, VH_PP_SMI>(acc, e, m_w, n_w, lane_e, n_full, stage_epi, wave);
-            else if constexpr (F8 && EPI == VH_EPI_RESID_LN)
+            else if constexpr (F8 && (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT))
                 gemm_epilogue<E4M3, EPI, MI, NI, 4, false>(acc, e, m_w, n_w, lane_e, n_full, m_full, stage_epi, wave);
             else
                 gemm_epilogue<T, EPI, MI, NI, (epi_is_16bit(EPI) ? VH_PP_SMI : 4), false>(acc, e, m_w, n_w, lane_e, n_full, m_full, stage_epi, wave);   // fp32 forms: 32 rows per pass
@@ -601,6 +602,8 @@ hipError_t launch_gemm_fp8(const GemmArgs& g, hipStream_t s) {
         case VH_EPI_LNFOLD: return g.wscale && g.stats && g.aux ? launch_pp<BF16, VH_EPI_LNFOLD, true>(g, mode, s) : hipErrorInvalidValue;
         case VH_EPI_LNFOLD_GELU: return g.wscale && g.stats && g.aux && g.N % 256 == 0 ? launch_pp<BF16, VH_EPI_LNFOLD_GELU, true>(g, mode, s) : hipErrorInvalidValue;
         case VH_EPI_RESID_LN: return g.out16 && g.partials && g.N % 256 == 0 ? launch_pp<BF16, VH_EPI_RESID_LN, true>(g, mode, s) : hipErrorInvalidValue;
+        // split residual of the fp8 path: out = the e4m3 hi plane (the next GEMM's operand), out16 = the bf16 lo plane
+        case VH_EPI_RESID_SPLIT: return g.out16 && g.partials && g.N % 256 == 0 ? launch_pp<BF16, VH_EPI_RESID_SPLIT, true>(g, mode, s) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

@@ -441,7 +441,7 @@ hipError_t launch_mlp_update(float* w, float* b, const float* d, const float* x,
 template <typename T, int CH>
 __global__ void __launch_bounds__(256)
 rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float eps, typename T::elem* __restrict__ x16,
-                     float* __restrict__ stats, uint8_t* __restrict__ xlo) {   // xlo != NULL: the split residual's lo plane (one byte per element)
+                     float* __restrict__ stats, void* __restrict__ xlo_) {   // xlo != NULL: the split residual's lo plane (16-bit T: one byte per element; T = e4m3: bf16)
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -468,8 +468,17 @@ rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float e
             const typename T::vec4 hq = pack4<T>(v[i][0], v[i][1], v[i][2], v[i][3]);
             *(typename T::vec4*)(x16 + row * dim + 4 * c) = hq;
             if constexpr (!std::is_same<T, E4M3>::value) {
+                uint8_t* const xlo = (uint8_t*)xlo_;
                 if (xlo) *(uint32_t*)(xlo + row * dim + 4 * c) = lo8_pack4<T>(v[i][0] - (float)hq[0], v[i][1] - (float)hq[1],
                                                                             v[i][2] - (float)hq[2], v[i][3] - (float)hq[3]);
+            } else {
+                typename BF16::elem* const xlo = (typename BF16::elem*)xlo_;
+                if (xlo) {   // fp8 path: hi = the e4m3 bytes just written, lo = bf16 of what they dropped
+                    const uint32_t w = (uint32_t)hq;
+                    *(typename BF16::vec4*)(xlo + row * dim + 4 * c) =
+                        pack4<BF16>(v[i][0] - __builtin_amdgcn_cvt_f32_fp8((int)w, 0), v[i][1] - __builtin_amdgcn_cvt_f32_fp8((int)w, 1),
+                                    v[i][2] - __builtin_amdgcn_cvt_f32_fp8((int)w, 2), v[i][3] - __builtin_amdgcn_cvt_f32_fp8((int)w, 3));
+                }
             }
         }
     }
@@ -482,7 +491,7 @@ template <typename T>
 static hipError_t rowstats_t(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, hipStream_t s, void* xlo = nullptr) {
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     auto o = (typename T::elem*)x16;
-    auto lo = (uint8_t*)xlo;
+    void* const lo = xlo;
     if (dim <= 256) hipLaunchKernelGGL((rowstats_cast_kernel<T, 1>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
     else if (dim <= 512) hipLaunchKernelGGL((rowstats_cast_kernel<T, 2>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
     else if (dim <= 768) hipLaunchKernelGGL((rowstats_cast_kernel<T, 3>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
@@ -502,6 +511,7 @@ hipError_t launch_rowstats_cast(const float* x, int64_t rows, int dim, float eps
 hipError_t launch_rowstats_split(const float* x, int64_t rows, int dim, float eps, void* hi, void* lo, float* stats, int dtype,
                                  hipStream_t s) {
     if (rows <= 0 || dim <= 0 || (dim & 3) || !lo) return hipErrorInvalidValue;
+    if (dtype == VH_DTYPE_FP8) return rowstats_t<E4M3>(x, rows, dim, eps, hi, stats, s, lo);   // e4m3 hi plane + bf16 lo plane
     return dtype == VH_DTYPE_BF16 ? rowstats_t<BF16>(x, rows, dim, eps, hi, stats, s, lo)
                                   : rowstats_t<FP16>(x, rows, dim, eps, hi, stats, s, lo);
 }
@@ -510,34 +520,42 @@ hipError_t launch_rowstats_split(const float* x, int64_t rows, int dim, float ep
 // CLS rows in front of the fp32 head.  One wave per row, two-pass statistics like layernorm_kernel.
 template <typename T>
 __global__ void __launch_bounds__(256)
-layernorm_split_kernel(const typename T::elem* __restrict__ hi, const uint8_t* __restrict__ lo, int64_t rows, int dim,
+layernorm_split_kernel(const typename T::elem* __restrict__ hi, const void* __restrict__ lo_, int64_t rows, int dim,
                        int64_t row_stride, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                        float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const typename T::elem* hr = hi + row * row_stride;
-    const uint8_t* lr = lo + row * row_stride;
+    // x[k] = hi + lo: 16-bit hi + scaled e4m3 byte, or (fp8 path) e4m3 hi + bf16 lo
+    auto xk = [&](int k) {
+        if constexpr (std::is_same<T, E4M3>::value)
+            return __builtin_amdgcn_cvt_f32_fp8((int)hr[k], 0) + (float)((const typename BF16::elem*)lo_ + row * row_stride)[k];
+        else
+            return (float)hr[k] + lo8_unpack1<T>(((const uint8_t*)lo_ + row * row_stride)[k]);
+    };
     float sum = 0.f;
-    for (int k = lane; k < dim; k += 64) sum += (float)hr[k] + lo8_unpack1<T>(lr[k]);
+    for (int k = lane; k < dim; k += 64) sum += xk(k);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum / (float)dim;
     float var = 0.f;
-    for (int k = lane; k < dim; k += 64) { const float d = ((float)hr[k] + lo8_unpack1<T>(lr[k])) - mean; var += d * d; }
+    for (int k = lane; k < dim; k += 64) { const float d = (xk(k)) - mean; var += d * d; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
     const float rstd = 1.0f / sqrtf(var / (float)dim + eps);
-    for (int k = lane; k < dim; k += 64) out[row * dim + k] = (((float)hr[k] + lo8_unpack1<T>(lr[k])) - mean) * rstd * gamma[k] + beta[k];
+    for (int k = lane; k < dim; k += 64) out[row * dim + k] = ((xk(k)) - mean) * rstd * gamma[k] + beta[k];
 }
 hipError_t launch_layernorm_split(const void* hi, const void* lo, int64_t rows, int dim, int64_t row_stride, const float* gamma,
                                   const float* beta, float eps, float* out32, int dtype, hipStream_t s) {
     if (rows <= 0 || dim <= 0) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (dtype == VH_DTYPE_BF16)
-        hipLaunchKernelGGL(layernorm_split_kernel<BF16>, grid, block, 0, s, (const BF16::elem*)hi, (const uint8_t*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
+    if (dtype == VH_DTYPE_FP8)
+        hipLaunchKernelGGL(layernorm_split_kernel<E4M3>, grid, block, 0, s, (const E4M3::elem*)hi, lo, rows, dim, row_stride, gamma, beta, eps, out32);
+    else if (dtype == VH_DTYPE_BF16)
+        hipLaunchKernelGGL(layernorm_split_kernel<BF16>, grid, block, 0, s, (const BF16::elem*)hi, (const void*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
     else
-        hipLaunchKernelGGL(layernorm_split_kernel<FP16>, grid, block, 0, s, (const FP16::elem*)hi, (const uint8_t*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
+        hipLaunchKernelGGL(layernorm_split_kernel<FP16>, grid, block, 0, s, (const FP16::elem*)hi, (const void*)lo, rows, dim, row_stride, gamma, beta, eps, out32);
     return hipGetLastError();
 }
 

@@ -407,7 +407,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     float* const stats_p = c->stats + r0 * 2;
     float* const partials_p = c->partials + (size_t)(D / 64) * r0 * 2;
     char* const xn16 = (char*)c->xn16 + r0 * D * esz_op;
-    char* const xlo16 = (char*)c->xlo16 + r0 * D;   // the lo plane: one byte per element
+    char* const xlo16 = (char*)c->xlo16 + r0 * D * (c->fp8 ? 2 : 1);   // the lo plane: one byte per element (fp8 path: bf16 beside the e4m3 hi plane)
     char* const qkv16 = (char*)c->qkv16 + r0 * 3 * D * esz;
     char* const att16 = (char*)c->att16 + r0 * D * esz_op;
     char* const h16 = (char*)c->h16 + r0 * M * esz_op;
@@ -457,7 +457,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, col16, dt16, s));
     if ((rc = mark(ST_IM2COL))) return rc;
     const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
-    if (c->split && nl > 0) {
+    if (c->split && !c->fp8 && nl > 0) {
         // Split residual: the patch embedding lands DIRECTLY in the two 16-bit planes, with the first row statistics'
         // partial sums (PATCH_SPLIT epilogue; the class-token rows from their own small kernel) -- no fp32 x, no separate
         // row-statistics pass over it (round 3: -0.1 ms per forward).  The partial sums are laid out for rows_g rows, like
@@ -477,7 +477,8 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = mark(ST_CLS))) return rc;
         if (c->ln_fold && nl > 0) {
             // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
-            if (c->split) HIPCHK(&c->err, launch_rowstats_split(x, rows_g, D, f.ln_eps, xn16, xlo16, stats_p, dt16, s));
+            // (fp8 path with the split residual: the patch embedding stays the bf16 fp32-out GEMM; this pass makes the planes)
+            if (c->split) HIPCHK(&c->err, launch_rowstats_split(x, rows_g, D, f.ln_eps, xn16, xlo16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s));
             else HIPCHK(&c->err, launch_rowstats_cast(x, rows_g, D, f.ln_eps, xn16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s));
             HIPCHK(&c->err, launch_ln_guard(stats_p, rows, c->guard_dev, s));   // real rows only (rows_g - rows are tile padding)
             if ((rc = mark(ST_LNSTATS))) return rc;
@@ -498,7 +499,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
-        if (c->split) HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, xn16, rows_g, D, D, VH_EPI_RESID_SPLIT, nullptr, 0));
+        if (c->split) HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, xn16, rows_g, D, D, VH_EPI_RESID_SPLIT, nullptr, 0, so));
         else HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows_g, D, D, VH_EPI_RESID_LN, nullptr, 0, so));
         if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
@@ -509,7 +510,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_FC1))) return rc;
         if ((rc = mark(ST_FC1))) return rc;
         if ((rc = tmark(ST_FC2))) return rc;
-        if (c->split) HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, xn16, rows_g, D, M, VH_EPI_RESID_SPLIT, nullptr, 0));
+        if (c->split) HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, xn16, rows_g, D, M, VH_EPI_RESID_SPLIT, nullptr, 0, s2));
         else HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, x, rows_g, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0, s2));
         if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
@@ -601,7 +602,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
                                 more ? P + L.layer[l + 1].ln1b : nullptr, ST_FC2))) return rc;
     }
     if (c->split && nl > 0)
-        HIPCHK(&c->err, launch_layernorm_split(xn16, xlo16, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn32, dt16, s));
+        HIPCHK(&c->err, launch_layernorm_split(xn16, xlo16, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn32, c->fp8 ? VH_DTYPE_FP8 : dt16, s));
     else
         HIPCHK(&c->err, launch_layernorm(x, batch, D, (int64_t)T * D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn32, VH_DTYPE_F32_INTERNAL, s));
     if ((rc = mark(ST_LNF))) return rc;
@@ -859,9 +860,9 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     c->fp8 = cfg->dtype == VH_DTYPE_FP8;
     c->dt16 = c->fp8 ? VH_DTYPE_BF16 : cfg->dtype;
     {
-        // (fp8 operands: the fold runs on an e4m3 copy of the raw rows and keeps the fp32 residual -- no split planes)
+        // (fp8 operands: the hi plane is e4m3 -- the GEMM operand itself -- and the lo plane bf16: 3 bytes per element as well)
         const char* e = getenv("VH_RESID_SPLIT");
-        c->split = c->ln_fold && !c->fp8 && !(e && e[0] == '0');
+        c->split = c->ln_fold && !(e && e[0] == '0');
         c->ln_fold_cfg = c->ln_fold;
         c->split_cfg = c->split;
     }
@@ -892,7 +893,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
                  o_att = carve(rows_p * D * 2), o_h = carve(rows_p * M * 2), o_col = carve(B * L.NP * (size_t)L.KP * 2),
                  o_cls = carve(B * D * 4),
                  o_in = carve(B * (size_t)cfg->image_size * cfg->image_size * cfg->channels * 4), o_lg = carve(B * C * 4),
-                 o_st = carve(rows_p * 2 * 4), o_pt = carve((D / 64 + 1) * rows_p * 2 * 4), o_xlo = carve(rows_p * D),
+                 o_st = carve(rows_p * 2 * 4), o_pt = carve((D / 64 + 1) * rows_p * 2 * 4), o_xlo = carve(rows_p * D * 2),   // lo plane: one byte per element (16-bit paths) or bf16 (fp8 path)
                  o_tk = carve(B * 4 * (size_t)(cfg->layers > 0 ? cfg->layers : 1)),   // attention work-queue counters: one word per image and layer, a part uses its first image's
                  o_gd = carve(256);     // the LayerNorm-fold guard word
     CK(hipMalloc((void**)&c->arena, a));
@@ -1474,21 +1475,29 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
         if (n_floats != n) return fail(&c->err, VH_ERR_INVALID, "expected %zu floats", n);
         const int nl = (c->run_layers < 0 || c->run_layers > c->cfg.layers) ? c->cfg.layers : c->run_layers;
         if (c->split && nl > 0) {   // the residual stream lives as two planes: x = hi (16 bit) + lo (one scaled e4m3 byte)
+            auto f = [&](uint16_t b, int dt) {
+                if (dt == VH_DTYPE_BF16) { uint32_t u = (uint32_t)b << 16; float v; memcpy(&v, &u, 4); return v; }
+                _Float16 hv; memcpy(&hv, &b, 2); return (float)hv;
+            };
+            auto g = [&](uint8_t b) {   // OCP e4m3fn -> float
+                const int e = (b >> 3) & 15, m = b & 7;
+                float v = e ? ldexpf(1.f + m / 8.f, e - 7) : ldexpf(m / 8.f, -6);
+                return (b & 0x80) ? -v : v;
+            };
+            if (c->fp8) {   // e4m3 hi plane (the GEMM operand) + bf16 lo plane
+                std::vector<uint8_t> hi(n);
+                std::vector<uint16_t> lo(n);
+                HIPCHK(&c->err, hipMemcpy(hi.data(), c->xn16, n, hipMemcpyDeviceToHost));
+                HIPCHK(&c->err, hipMemcpy(lo.data(), c->xlo16, n * 2, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < n; ++i) host_out[i] = g(hi[i]) + f(lo[i], VH_DTYPE_BF16);
+                return VH_OK;
+            }
             std::vector<uint16_t> hi(n);
             std::vector<uint8_t> lo(n);
             HIPCHK(&c->err, hipMemcpy(hi.data(), c->xn16, n * 2, hipMemcpyDeviceToHost));
             HIPCHK(&c->err, hipMemcpy(lo.data(), c->xlo16, n, hipMemcpyDeviceToHost));
-            auto f = [&](uint16_t b) {
-                if (c->dt16 == VH_DTYPE_BF16) { uint32_t u = (uint32_t)b << 16; float v; memcpy(&v, &u, 4); return v; }
-                _Float16 hv; memcpy(&hv, &b, 2); return (float)hv;
-            };
-            auto g = [&](uint8_t b) {   // OCP e4m3fn -> float, then the plane's scale (vh_common.h Lo8<T>)
-                const int e = (b >> 3) & 15, m = b & 7;
-                float v = e ? ldexpf(1.f + m / 8.f, e - 7) : ldexpf(m / 8.f, -6);
-                if (b & 0x80) v = -v;
-                return v * (c->dt16 == VH_DTYPE_BF16 ? 1.f / 128.f : 1.f / 1024.f);
-            };
-            for (size_t i = 0; i < n; ++i) host_out[i] = f(hi[i]) + g(lo[i]);
+            const float inv = c->dt16 == VH_DTYPE_BF16 ? 1.f / 128.f : 1.f / 1024.f;   // the byte plane's scale (vh_common.h Lo8<T>)
+            for (size_t i = 0; i < n; ++i) host_out[i] = f(hi[i], c->dt16) + g(lo[i]) * inv;
             return VH_OK;
         }
         HIPCHK(&c->err, hipMemcpy(host_out, c->x, n * 4, hipMemcpyDeviceToHost));
@@ -1536,6 +1545,24 @@ int vh_op_gemm_fp8(const void* a8, const void* w8, const float* w_scale, const f
     if (epi != VH_EPI_BIAS && epi != VH_EPI_BIAS_GELU && epi != VH_EPI_BIAS_RESID && epi != VH_EPI_BIAS_F32)
         return fail(nullptr, VH_ERR_UNSUPPORTED, "gemm_fp8: epilogue %d not available", epi);
     GemmArgs g{a8, w8, bias, out, M, N, K, epi, w_scale, 0, VH_DTYPE_FP8, variant};
+    OPCHK(launch_gemm_fp8(g, (hipStream_t)stream));
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return VH_OK;
+}
+int vh_op_gemm_fp8_ex(const void* a8, const void* w8, const float* w_scale, const float* bias, void* out, int64_t M, int N, int K,
+                      int epi, const float* c_dev, const float* stats, void* out16, float* partials, int variant, void* stream) {
+    if (variant != 0 && variant != 5 && variant != 6 && variant != 7) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8_ex: variant must be 0, 5, 6 or 7");
+    if (!a8 || !w8 || !w_scale || !bias || !out) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8_ex: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 4) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8_ex: need K %% 128 == 0 and N %% 4 == 0");
+    if (M > 0x7FFFFFFF / 2) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8_ex: M too large");
+    const bool fold = epi == VH_EPI_LNFOLD || epi == VH_EPI_LNFOLD_GELU, resid = epi == VH_EPI_RESID_LN || epi == VH_EPI_RESID_SPLIT;
+    if (!fold && !resid) return fail(nullptr, VH_ERR_UNSUPPORTED, "gemm_fp8_ex: epilogue %d not available", epi);
+    if (fold && (!c_dev || !stats)) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8_ex: LNFOLD needs c and stats");
+    if (resid && (!out16 || !partials)) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8_ex: RESID_* needs out16 and partials");
+    if ((resid || epi == VH_EPI_LNFOLD_GELU) && N % 256) return fail(nullptr, VH_ERR_INVALID, "gemm_fp8_ex: N %% 256 != 0");
+    GemmArgs g{a8, w8, bias, out, M, N, K, epi, fold ? c_dev : w_scale, 0, VH_DTYPE_FP8, variant};
+    if (fold) g.wscale = w_scale;
+    g.stats = stats; g.out16 = out16; g.partials = partials;
     OPCHK(launch_gemm_fp8(g, (hipStream_t)stream));
     OPCHK(hipStreamSynchronize((hipStream_t)stream));
     return VH_OK;

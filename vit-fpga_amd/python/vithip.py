@@ -97,6 +97,7 @@ SYMBOLS = {
     "vh_debug_set_layers": (_i, [_vp, _i]),
     "vh_op_gemm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "vh_op_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "vh_op_gemm_fp8_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "vh_op_quantize_rows": (_i, [_vp, _i, _i, C.c_float, _vp, _vp, _vp]),
     "vh_op_gemm_ex": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "vh_op_rowstats_cast": (_i, [_vp, _i64, _i, _f, _vp, _vp, _i, _vp]),
@@ -588,6 +589,12 @@ def op_gemm_fp8(a8_ptr, w8_ptr, scale_ptr, bias_ptr, out_ptr, M, N, K, epilogue,
 
 def op_quantize_rows(w_ptr, rows, cols, post_scale, w8_ptr, scale_ptr):
     _check(lib().vh_op_quantize_rows(w_ptr, rows, cols, post_scale, w8_ptr, scale_ptr, None))
+
+
+def op_gemm_fp8_ex(a8_ptr, w8_ptr, scale_ptr, bias_ptr, out_ptr, M, N, K, epilogue, c_ptr=None, stats_ptr=None, out16_ptr=None,
+                   partials_ptr=None, variant=0):
+    _check(lib().vh_op_gemm_fp8_ex(a8_ptr, w8_ptr, scale_ptr, bias_ptr, out_ptr, M, N, K, epilogue, c_ptr, stats_ptr, out16_ptr,
+                                   partials_ptr, variant, None))
 
 
 # ---- OCP e4m3fn on the host (table-driven; used to build / read fp8 operator operands in tests) ----
