@@ -9,6 +9,8 @@ set -e
 tag=$1; part=${2:-1}; out=gpurun_out; mkdir -p $out; export TMPDIR=/tmp
 D=$PWD/vit-fpga_amd/libvithip_diag.so
 NOX="--no-cpu-baseline --no-parity --no-fp16-line --no-extra-configs"
+# the stamped diagnostic library must be of THIS tree (a stale one misses new symbols and measures old kernels)
+if [ "$part" != 3 ]; then make -s -C vit-fpga_amd diag -j8 > /dev/null 2>&1 || { echo "make diag failed"; exit 1; }; fi
 if [ "$part" = 1 ]; then
 timeout -k 10 400 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
 echo "default bench done"; cut -c1-220 $out/${tag}_bench_default.json
