@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--no-fp16-line", action="store_true", help="skip the extra fp16 measurement of the default run")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short ViT-L/16-384 fp16 b256 and ViT-B/16 fp8 b512 measurements of the default run")
+    ap.add_argument("--cls-tail", action="store_true",
+                    help="VH_FLAG_CLS_TAIL: the last layer computes the class-token rows only (an opt-in of the library; a line "
+                         "measured with it says so in config.workload and is not the BASELINE configuration)")
     ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even with one rank")
     ap.add_argument("--stages", action="store_true", help="also print a per-stage time table to stderr")
     ap.add_argument("--host-path", action="store_true",
@@ -140,7 +143,7 @@ def main():
         if use_dist:
             dist.barrier()
 
-    def measure(dtype_name, extras, config=None, B=None, steps=None, warmup=None, parity_images=None):
+    def measure(dtype_name, extras, config=None, B=None, steps=None, warmup=None, parity_images=None, cls_tail=None):
         """One complete measurement with `dtype_name` operands: context, weights (broadcast when distributed), warm-up,
         K timed steps, roofline of the fc1 kernel, parity of the timed batch's first images."""
         config = config or args.config
@@ -153,7 +156,8 @@ def main():
         flops_img = S.flops_per_image(cfg)
         dt = {"bf16": vithip.DTYPE_BF16, "fp16": vithip.DTYPE_FP16, "fp8": vithip.DTYPE_FP8}[dtype_name]
         ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B, device=local_rank,
-                                flags=vithip.FLAG_W8_E4M3 if args.weights == "e4m3" else 0)
+                                flags=(vithip.FLAG_W8_E4M3 if args.weights == "e4m3" else 0) |
+                                      (vithip.FLAG_CLS_TAIL if (args.cls_tail if cls_tail is None else cls_tail) else 0))
         if args.streams > 0:
             ctx.set_streams(args.streams)
         streams = ctx.get_streams()
@@ -291,6 +295,8 @@ def main():
         # BASELINE configs 4 and 5, short: about a second of GPU time each
         extra_res["vit_large_384_fp16_b256"] = measure("fp16", False, config="vit_large_384", B=256, steps=5, warmup=1, parity_images=2)
         extra_res["fp8_b512"] = measure("fp8", False, config="vit_base", B=512, steps=10, warmup=2, parity_images=8)
+        if not args.cls_tail:
+            extra_res["cls_tail_bf16_b512"] = measure("bf16", False, config="vit_base", B=512, steps=10, warmup=2, parity_images=8, cls_tail=True)
 
     if rank == 0:
         streams = main_res["streams"]
@@ -304,7 +310,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config} {cfg['image_size']}x{cfg['image_size']}x{cfg['channels']} inference, "
                                    f"{B} images per GPU resident in HBM, random-init weights (seed 0)"
-                                   + (", weight-only e4m3 (VH_FLAG_W8_E4M3)" if args.weights == "e4m3" else ""),
+                                   + (", weight-only e4m3 (VH_FLAG_W8_E4M3)" if args.weights == "e4m3" else "")
+                                   + (", VH_FLAG_CLS_TAIL (last layer: class-token rows only -- NOT the BASELINE configuration)" if args.cls_tail else ""),
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": par, "flop_per_image": flops_img},
             "forward_mfma_frac": main_res["forward_mfma_frac"],
             "roofline": main_res["roofline"],
@@ -318,6 +325,10 @@ def main():
             out[name] = {k: r[k] for k in ("value", "ms_per_step", "forward_mfma_frac", "roofline", "step_ms", "parity") if k in r}
             out[name]["steps"] = r["steps"]
             out[name]["note"] = ("BASELINE config 4: ViT-L/16 384x384 fp16, 256 images, 1 GPU (short run)" if name.startswith("vit_large")
+                                 else "NOT a BASELINE configuration and never `value`: the same bf16 batch-512 workload with the library's opt-in "
+                                      "VH_FLAG_CLS_TAIL -- the last layer runs attention for the class-token query only and out-proj / fc1 / "
+                                      "fc2 on the 512 class rows, i.e. it skips rows no logit depends on (forward_mfma_frac still counts the "
+                                      "full model's FLOP and therefore overstates the matrix work done here)" if name.startswith("cls_tail")
                                  else "BASELINE config 5: ViT-B/16, e4m3 operands in the four per-layer GEMMs (VH_DTYPE_FP8), 512 images, "
                                       "1 GPU (short run; fraction of the 5 PF dense fp8 peak)")
         if fp16_res:

@@ -99,6 +99,13 @@ typedef struct vh_config {
  * other reading of "fp8", both operands e4m3 on the scaled-MFMA path, is VH_DTYPE_FP8).  Throughput is that of the
  * 16-bit dtype: at batch 512 the weights are 0.3 % of a forward's HBM traffic, which is all a 1-byte copy would save. */
 #define VH_FLAG_W8_E4M3 4
+/* Class-token tail (opt-in): the logits depend on the LAST layer's class-token row only, so with this flag the last layer runs
+ * attention for that one query (all keys / values) and out-proj, fc1, fc2, the final LayerNorm and the head on `batch` rows
+ * instead of batch x tokens.  Logits agree with the default path to rounding (not bitwise: the one-query attention is a
+ * different kernel); the residual rows of the other tokens are NOT updated by the last layer (vh_debug_read of the hidden
+ * state returns them as of the layer before).  Folded 16-bit path only (ignored elsewhere).  Never used by the default bench
+ * line: a forward that skips rows is reported as its own `cls_tail` object. */
+#define VH_FLAG_CLS_TAIL 8
 
 typedef struct vh_ctx vh_ctx; /* opaque ViT context (device, stream, weights, workspace) */
 typedef struct vh_mlp vh_mlp; /* opaque MLP-mode context (the reference's real semantics)  */

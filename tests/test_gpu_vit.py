@@ -703,3 +703,39 @@ def test_mlp_mode_matches_oracle(act):
     many = m.forward(np.stack([x, -x, 0.5 * x]))
     assert np.array_equal(many[0], got)
     m.close()
+
+
+@pytest.mark.parametrize("dt", DT_PARAMS)
+def test_class_token_tail_flag_gives_the_full_forward_logits_to_rounding(dt):
+    """VH_FLAG_CLS_TAIL (opt-in): the last layer computes only what the logits need -- attention for the class-token query,
+    out-proj / fc1 / fc2 on the `batch` class rows.  Its logits must be the full forward's to rounding (the one-query attention
+    is another kernel, so not bitwise), inside the same tolerance against the oracle, deterministic and independent of what
+    else is in the batch; a model the folded path does not apply to ignores the flag (bitwise the default)."""
+    cfg = S.CONFIGS["vit_base"]
+    blob = S.make_blob(cfg, seed=0)
+    images = S.make_images(cfg, seed=1, batch=6)
+    ref = O.vit_forward(cfg, blob, images)
+    full = vithip.VitContext(cfg, dtype=dt, max_batch=6)
+    full.load_weights(blob)
+    want = full.forward(images)
+    full.close()
+    ctx = vithip.VitContext(cfg, dtype=dt, max_batch=6, flags=vithip.FLAG_CLS_TAIL)
+    ctx.load_weights(blob)
+    got = ctx.forward(images)
+    assert np.isfinite(got).all()
+    print(f"\n[cls tail] {NAME[dt]}: vs the full forward {rel(got, want):.3e}, vs the oracle {rel(got, ref):.3e} (full: {rel(want, ref):.3e})")
+    assert rel(got, want) <= (2e-4 if dt == vithip.DTYPE_FP16 else 2e-3)
+    assert rel(got, ref) <= TOL[dt]
+    assert np.array_equal(got, ctx.forward(images))
+    for lo, hi in ((0, 3), (4, 5), (5, 6)):
+        assert np.array_equal(ctx.forward(images[lo:hi]), got[lo:hi]), (lo, hi)
+    ctx.close()
+    tiny = S.CONFIGS["vit_tiny"]                      # dim 192: no fold, so no split planes and no tail
+    tb, ti = S.make_blob(tiny, 0), S.make_images(tiny, 1, 3)
+    outs = []
+    for flags in (0, vithip.FLAG_CLS_TAIL):
+        c2 = vithip.VitContext(tiny, dtype=dt, max_batch=3, flags=flags)
+        c2.load_weights(tb)
+        outs.append(c2.forward(ti))
+        c2.close()
+    assert np.array_equal(outs[0], outs[1])

@@ -799,6 +799,109 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     return hipGetLastError();
 }
 
+// ---- attention of the class token only (VH_FLAG_CLS_TAIL: the last layer computes what the logits need) ----------------
+// One wave per (image, head): the query is row 0 of the image (64 values, already scaled to the log2 domain like every q),
+// 8 lanes share a key row (16 bytes each: a wave instruction reads 8 whole rows), fp32 dot products, exp2-domain softmax over
+// the wave, then the same 8-lanes-per-row walk over the value rows with 8 output dimensions per lane.  Reads K and V once
+// (2/3 of q|k|v), writes [batch][dim]; no MFMA -- 6 144 items x 25 K MACs at ViT-B b512.
+template <typename T>
+__global__ void __launch_bounds__(256)
+attention_cls_kernel(const typename T::elem* __restrict__ qkv, typename T::elem* __restrict__ out, int batch, int tokens, int heads) {
+    using elem = typename T::elem;
+    using vec8 = typename T::vec8;
+    constexpr int MAXT = 1024;
+    __shared__ float sc[4][MAXT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wv;
+    if (item >= batch * heads) return;
+    const int b = item / heads, h = item - b * heads;
+    const int D = heads * 64;
+    const int64_t ld = 3 * (int64_t)D;
+    const elem* const base = qkv + (int64_t)b * tokens * ld + h * 64;
+    // 8 lanes per row: lane = 8 * g + c reads the 16-byte chunk c of row 8 * step + g, so one wave instruction covers 8 whole
+    // 128-byte rows
+    const int g = lane >> 3, c = lane & 7;
+    float q[8];
+    {
+        const vec8 v = *(const vec8*)(base + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = (float)v[j];
+    }
+    float mx = -INFINITY;
+    constexpr int U = 4;   // row groups per step: U independent 16-byte loads in flight per lane (the walk is latency-bound)
+    for (int t0 = 0; t0 < tokens; t0 += 8 * U) {
+        vec8 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + 8 * u + g;
+            v[u] = *(const vec8*)(base + (t < tokens ? t : tokens - 1) * ld + D + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + 8 * u + g;
+            float sv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv = fmaf(q[j], (float)v[u][j], sv);
+            sv += __shfl_xor(sv, 1); sv += __shfl_xor(sv, 2); sv += __shfl_xor(sv, 4);   // the row's 8 lanes
+            if (t < tokens) {
+                if (c == 0) sc[wv][t] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // the wave's LDS writes have landed (its slice is private: no barrier)
+    float sum = 0.f;
+    for (int t = lane; t < tokens; t += 64) {
+        const float p = __builtin_amdgcn_exp2f(sc[wv][t] - mx);
+        sc[wv][t] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    // P V: the lane accumulates its 8 output dimensions (chunk c) over the rows g, g + 8, ...; the 8 row groups are added at the end
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < tokens; t0 += 8 * U) {
+        vec8 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + 8 * u + g;
+            v[u] = *(const vec8*)(base + (t < tokens ? t : tokens - 1) * ld + 2 * D + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + 8 * u + g;
+            const float p = t < tokens ? sc[wv][t] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(p, (float)v[u][j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc[j] += __shfl_xor(acc[j], 8); acc[j] += __shfl_xor(acc[j], 16); acc[j] += __shfl_xor(acc[j], 32);
+    }
+    if (g == 0) {
+        const float r = 1.0f / sum;
+        vec8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (elem)(acc[j] * r);
+        *(vec8*)(out + (int64_t)b * D + h * 64 + c * 8) = o;
+    }
+}
+hipError_t launch_attention_cls(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype, hipStream_t s) {
+    if (batch <= 0 || tokens <= 0 || tokens > 1024 || heads <= 0) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((batch * heads + 3) / 4));
+    if (dtype == VH_DTYPE_BF16)
+        hipLaunchKernelGGL(attention_cls_kernel<BF16>, grid, dim3(256), 0, s, (const BF16::elem*)qkv16, (BF16::elem*)out16, batch, tokens, heads);
+    else if (dtype == VH_DTYPE_FP16)
+        hipLaunchKernelGGL(attention_cls_kernel<FP16>, grid, dim3(256), 0, s, (const FP16::elem*)qkv16, (FP16::elem*)out16, batch, tokens, heads);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype,
                             unsigned int* ticket, hipStream_t s, bool ticket_zeroed) {
     if (batch <= 0 || tokens <= 0 || heads <= 0) return hipErrorInvalidValue;

@@ -65,6 +65,8 @@ constexpr float kAttnQScale = 0.125f * 1.4426950408889634f;
 // equal static shares per workgroup
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16,
                             int dtype, unsigned int* ticket, hipStream_t stream, bool ticket_zeroed = false);
+// class-token query only: out16 [batch][heads * 64] (VH_FLAG_CLS_TAIL); 16-bit dtypes, tokens <= 1024
+hipError_t launch_attention_cls(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype, hipStream_t stream);
 size_t attention_lds_bytes(int tokens);
 hipError_t launch_im2col(const float* in_nhwc, int batch, int image, int patch, int channels,
                          void* out16, int dtype, hipStream_t stream);

@@ -121,7 +121,7 @@ const char* check_config(const vh_config& c) {
     if (c.dtype == VH_DTYPE_FP8 && (c.dim % 128 || c.mlp_dim % 128)) return "VH_DTYPE_FP8 needs dim and mlp_dim to be multiples of 128";
     if (c.max_batch <= 0) return "max_batch must be positive";
     if (!(c.ln_eps > 0.f)) return "ln_eps must be positive";
-    if (c.flags & ~(VH_FLAG_LN_FOLD_OFF | VH_FLAG_LN_FOLD_ON | VH_FLAG_W8_E4M3)) return "unknown bits in flags";
+    if (c.flags & ~(VH_FLAG_LN_FOLD_OFF | VH_FLAG_LN_FOLD_ON | VH_FLAG_W8_E4M3 | VH_FLAG_CLS_TAIL)) return "unknown bits in flags";
     if ((c.flags & VH_FLAG_W8_E4M3) && c.dtype == VH_DTYPE_FP8) return "flags: VH_FLAG_W8_E4M3 is for the 16-bit dtypes (VH_DTYPE_FP8 quantises both operands)";
     if ((c.flags & VH_FLAG_W8_E4M3) && (c.dim % 4 || c.mlp_dim % 4)) return "flags: VH_FLAG_W8_E4M3 needs dim and mlp_dim multiples of 4";
     if ((c.flags & VH_FLAG_LN_FOLD_OFF) && (c.flags & VH_FLAG_LN_FOLD_ON)) return "flags: VH_FLAG_LN_FOLD_OFF and VH_FLAG_LN_FOLD_ON exclude each other";
@@ -175,6 +175,7 @@ struct vh_ctx {
     // 3 B per element each way instead of the fp32 array plus its 16-bit copy.
     // VH_RESID_SPLIT=0 (A/B tools) keeps the fp32 array.
     bool split = false;
+    bool cls_tail = false;    // VH_FLAG_CLS_TAIL: the last layer computes the class-token rows only (folded 16-bit path)
     void* xlo16 = nullptr;    // [B*T, D] bytes
     // Run-time guard on the fold: the kernels that produce the row statistics keep a running maximum of
     // |mean| * rstd over the REAL rows (guard_dev: the bits of a non-negative float); every forward ends with an
@@ -484,6 +485,9 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
             if ((rc = mark(ST_LNSTATS))) return rc;
         }
     }
+    // the class-token tail needs the split planes of the folded 16-bit path, the whole model, and room in the patch-matrix buffer
+    const bool tail = c->cls_tail && c->ln_fold && c->split && !c->fp8 && nl == f.layers && c->run_layers < 0 && T <= 1024 &&
+                      (size_t)L.NP * L.KP * esz >= 2 * ((size_t)D * esz + 256);
     for (int l = 0; l < nl && c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
         const float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
@@ -494,6 +498,38 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         HIPCHK(&c->err, gemm(xn16, c->wqkv16[l], cd + 3 * D, qkv16, rows_g, 3 * D, D, VH_EPI_LNFOLD, cd, 0, sq));
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
+        if (tail && l + 1 == nl) {
+            // VH_FLAG_CLS_TAIL, last layer: only the class-token row of every image reaches the head, so attention runs for that
+            // one query (all keys and values), and out-proj, fc1 and fc2 run on the `batch` class rows, gathered into compact
+            // planes (the idle patch-matrix buffer).  Same kernels, same per-row arithmetic as the full layer, except the
+            // attention row (a VALU kernel with another summation order): logits agree to rounding, not bitwise.
+            char* const hc = col16;
+            char* const lc = col16 + (((size_t)batch * D * esz + 255) & ~(size_t)255);
+            HIPCHK(&c->err, launch_attention_cls(qkv16, batch, T, f.heads, att16, dt16, s));
+            if ((rc = mark(ST_ATTN))) return rc;
+            HIPCHK(&c->err, hipMemcpy2DAsync(hc, (size_t)D * esz, xn16, (size_t)T * D * esz, (size_t)D * esz, batch, hipMemcpyDeviceToDevice, s));
+            HIPCHK(&c->err, hipMemcpy2DAsync(lc, (size_t)D, xlo16, (size_t)T * D, (size_t)D, batch, hipMemcpyDeviceToDevice, s));
+            GemmArgs gp{att16, c->wo16[l], P + o.ob, hc, batch, D, D, VH_EPI_RESID_SPLIT, nullptr, 0, dt16, 0};
+            gp.out16 = lc; gp.partials = partials_p;
+            HIPCHK(&c->err, launch_gemm(gp, s));
+            if ((rc = mark(ST_PROJ))) return rc;
+            HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, batch, D, f.ln_eps, stats_p, s, batch, c->guard_dev));
+            if ((rc = mark(ST_LNSTATS))) return rc;
+            GemmArgs g1{hc, c->w1_16[l], cd + 6 * D + M, h16, batch, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0, dt16, 0};
+            g1.stats = stats_p;
+            HIPCHK(&c->err, launch_gemm(g1, s));
+            if ((rc = mark(ST_FC1))) return rc;
+            GemmArgs g2{h16, c->w2_16[l], P + o.f2b, hc, batch, D, M, VH_EPI_RESID_SPLIT, nullptr, 0, dt16, 0};
+            g2.out16 = lc; g2.partials = partials_p;
+            HIPCHK(&c->err, launch_gemm(g2, s));
+            if ((rc = mark(ST_FC2))) return rc;
+            HIPCHK(&c->err, launch_layernorm_split(hc, lc, batch, D, D, P + L.lnfw, P + L.lnfb, f.ln_eps, clsn32, dt16, s));
+            if ((rc = mark(ST_LNF))) return rc;
+            HIPCHK(&c->err, launch_head_f32(clsn32, P + L.headw, P + L.headb, logits, batch, f.classes, D, s));
+            if ((rc = mark(ST_HEAD))) return rc;
+            c->last_batch = batch;
+            return VH_OK;
+        }
         if ((rc = tmark(ST_ATTN))) return rc;
         HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, tickets_part + l, s, true));
         if ((rc = tmark(ST_ATTN))) return rc;
@@ -865,6 +901,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         c->split = c->ln_fold && !(e && e[0] == '0');
         c->ln_fold_cfg = c->ln_fold;
         c->split_cfg = c->split;
+        c->cls_tail = (cfg->flags & VH_FLAG_CLS_TAIL) != 0;
     }
     CK(hipHostMalloc((void**)&c->guard_host, 64, hipHostMallocDefault));
     *c->guard_host = 0.f;

@@ -15,7 +15,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 LIB_PATH = os.environ.get("VITHIP_LIB") or os.path.join(PKG_ROOT, "libvithip.so")   # VITHIP_LIB: A/B builds (tools/)
 
 DTYPE_BF16, DTYPE_FP16, DTYPE_FP8 = 0, 1, 2
-FLAG_LN_FOLD_OFF, FLAG_LN_FOLD_ON, FLAG_W8_E4M3 = 1, 2, 4   # vh_config.flags
+FLAG_LN_FOLD_OFF, FLAG_LN_FOLD_ON, FLAG_W8_E4M3, FLAG_CLS_TAIL = 1, 2, 4, 8   # vh_config.flags
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH, EPI_LNFOLD, EPI_LNFOLD_GELU, EPI_RESID_LN, EPI_RESID_SPLIT, EPI_PATCH_SPLIT = range(10)
 ACT_IDENTITY, ACT_RELU2, ACT_RELU, ACT_HARDTANH, ACT_GELU = range(5)
 
