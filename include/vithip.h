@@ -258,7 +258,7 @@ int vh_debug_set_layers(vh_ctx* ctx, int n_layers);
 #define VH_EPI_LNFOLD_GELU 6 /* gelu of the above                                          */
 #define VH_EPI_RESID_LN 7    /* out32 += acc + bias; out16 = 16-bit copy; partials[N/64][M][2] = row (sum, sumsq) */
 #define VH_EPI_RESID_SPLIT 8 /* residual kept as TWO planes, x = hi + lo: (hi, lo) += acc + bias with hi = T(x) (16 bit) and lo = what that
-                                rounding dropped, ONE byte per element: e4m3((x - hi) * 128) for bf16, * 1024 for fp16 (12 / 15
+                                rounding dropped, ONE byte per element: e4m3((x - hi) * 32) for bf16, * 256 for fp16 (12 / 15
                                 significant bits of x in the pair).  out = hi plane (the next GEMM's A operand), out16 = lo plane
                                 [M,N] bytes, partials as RESID_LN.  3 B per element each way instead of 4 B + the 2 B copy of RESID_LN */
 #define VH_EPI_PATCH_SPLIT 9 /* the patch embedding written directly as the split residual: row(m) of (hi, lo) = the planes of

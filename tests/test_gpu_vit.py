@@ -739,3 +739,34 @@ def test_class_token_tail_flag_gives_the_full_forward_logits_to_rounding(dt):
         outs.append(c2.forward(ti))
         c2.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_massive_activations_do_not_saturate_the_one_byte_lo_plane():
+    """Trained ViTs carry a few "massive activations": single channels of the residual stream at hundreds to thousands while
+    the rest is O(1).  The split residual's lo byte holds (x - hi) * 256 (fp16) / * 32 (bf16) in e4m3, i.e. at most |x| / 8:
+    it saturates only beyond |x| = 3 584.  Drive one channel to about 2 000 through the position embedding and check that the
+    folded default path (planes) is as close to the fp32 oracle as the stand-alone path (fp32 residual) is."""
+    cfg = S.CONFIGS["vit_base"]
+    t = S.make_tensors(cfg, 0)
+    t["pos"] = t["pos"].copy()
+    t["pos"][..., 301] += np.float32(2000.0)
+    blob = S.pack_blob(cfg, t)
+    images = S.make_images(cfg, 1, 4)
+    ref, hid = O.vit_forward(cfg, blob, images, want_hidden=True)
+    assert np.abs(hid[..., 301]).max() > 1500.0           # the channel is still massive after the last layer
+    err = {}
+    for flags in (vithip.FLAG_LN_FOLD_OFF, 0):
+        ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=4, flags=flags)
+        ctx.load_weights(blob)
+        got = ctx.forward(images)
+        err[flags] = rel(got, ref)
+        if flags == 0:
+            seen, thresh, tripped = ctx.ln_guard()
+            assert ctx.ln_fold() and not tripped, (seen, thresh)
+            x = ctx.debug_read(0, hid.size).reshape(hid.shape)
+            # the planes reproduce the massive channel to the pair's precision (2^-15 of its value), not to fp16's 2^-11
+            assert np.abs(x[..., 301] - hid[..., 301]).max() <= 2e-3 * np.abs(hid[..., 301]).max()
+        ctx.close()
+    print(f"\n[massive] one channel at ~2000: stand-alone {err[vithip.FLAG_LN_FOLD_OFF]:.3e}, folded + planes {err[0]:.3e}")
+    assert np.isfinite(list(err.values())).all()
+    assert err[0] <= max(NORTH_STAR, 1.25 * err[vithip.FLAG_LN_FOLD_OFF])

@@ -1533,7 +1533,7 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
             std::vector<uint8_t> lo(n);
             HIPCHK(&c->err, hipMemcpy(hi.data(), c->xn16, n * 2, hipMemcpyDeviceToHost));
             HIPCHK(&c->err, hipMemcpy(lo.data(), c->xlo16, n, hipMemcpyDeviceToHost));
-            const float inv = c->dt16 == VH_DTYPE_BF16 ? 1.f / 128.f : 1.f / 1024.f;   // the byte plane's scale (vh_common.h Lo8<T>)
+            const float inv = c->dt16 == VH_DTYPE_BF16 ? 1.f / 32.f : 1.f / 256.f;   // the byte plane's scale (vh_common.h Lo8<T>)
             for (size_t i = 0; i < n; ++i) host_out[i] = f(hi[i], c->dt16) + g(lo[i]) * inv;
             return VH_OK;
         }

@@ -623,7 +623,7 @@ def to_e4m3(x):
 
 
 # ---- the lo plane of the split residual: one e4m3 byte per element, scaled (csrc/vh_common.h Lo8) ----
-LO8_SCALE = {DTYPE_BF16: 128.0, DTYPE_FP16: 1024.0}
+LO8_SCALE = {DTYPE_BF16: 32.0, DTYPE_FP16: 256.0}
 
 
 def to_lo8(residue, dtype):
