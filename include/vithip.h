@@ -80,10 +80,22 @@ typedef struct vh_config {
  * 16-bit-rounded residual rows, whose rounding error relative to the centred signal grows with
  * sqrt(1 + (row mean / row sigma)^2).  Three settings:
  *   flags == 0 (default)   the GUARDED fold: folded, and every forward measures max |mean| / sigma over its rows
- *                          (vh_get_ln_guard).  Once a completed forward has exceeded the threshold (0.5; environment
- *                          VH_LN_GUARD) the context switches to the stand-alone LayerNorm for good (the weights are
- *                          prepared again from the resident blob), and the synchronous vh_forward repeats the very
- *                          forward that tripped it, so what it returns is always inside the fold's error budget.
+ *                          (vh_get_ln_guard).  The decision is taken first WHEN THE WEIGHTS ARE LOADED: every vh_load_weights* /
+ *                          vh_init_weights_seeded ends with one calibration forward of a seeded image, and a checkpoint whose
+ *                          rows exceed the threshold (0.5; environment VH_LN_GUARD) -- a property of the weights far more than
+ *                          of the image -- leaves the load on the stand-alone LayerNorm, so no entry point, asynchronous
+ *                          ones included, ever returns a batch from a fold the weights had tripped.  Behind that, every
+ *                          forward still measures: once a COMPLETED forward has exceeded the threshold because of its DATA
+ *                          the context switches for good (the weights are prepared again from the resident blob) at the
+ *                          next forward entry or vh_synchronize; the synchronous vh_forward repeats the very forward that
+ *                          tripped it, the asynchronous entry points have by then delivered that batch from the folded
+ *                          path (vh_get_ln_guard reports `tripped`), and from then on logit bits differ from a context
+ *                          that never tripped -- bit-reproducibility across runs holds for ON / OFF, and for the default
+ *                          as long as no input trips the backstop.
+ *                          VH_DTYPE_FP8 contexts guard a second quantity: the folded GEMMs multiply the RAW residual rows
+ *                          as e4m3, which saturates at 448, so the statistics kernels also track max |x| (vh_get_fp8_guard)
+ *                          and rows beyond 448 switch the context to the stand-alone LayerNorm operand (normalised values
+ *                          fit e4m3) in the same way, calibration forward included.
  *   VH_FLAG_LN_FOLD_ON     always folded: the explicit throughput choice.  The guard still measures, never switches.
  *   VH_FLAG_LN_FOLD_OFF    always the stand-alone LayerNorm kernel.
  * With ON or OFF the path depends on the model shape and the flags ONLY (never on max_batch or on the data), so a given
@@ -138,6 +150,11 @@ int vh_get_ln_fold(const vh_ctx* ctx, int* on);
  * row has shown since the weights were loaded (0 when the context never folded), *threshold = the switch point,
  * *tripped = 1 once it was exceeded.  Synchronises the context's stream.  Any pointer may be NULL. */
 int vh_get_ln_guard(vh_ctx* ctx, float* max_ratio, float* threshold, int* tripped);
+/* VH_DTYPE_FP8 contexts: *max_abs = the largest |x| (an upper bound of it: the root sum of squares of a row's largest
+ * 64-column block; exact for layer 0) any residual row has shown since the weights were loaded, *limit = 448 (e4m3).  Beyond
+ * the limit the guarded fold switches to the stand-alone LayerNorm (vh_get_ln_guard reports `tripped`).  0 for 16-bit
+ * contexts.  Synchronises the context's stream.  Either pointer may be NULL. */
+int vh_get_fp8_guard(vh_ctx* ctx, float* max_abs, float* limit);
 
 /* Weight blob = fp32 tensors in canonical order (DESIGN.md "weight blob") preceded by a
  * 64-byte header.  Replaces _load_params (netFPGA.cpp:484-515): uploads, converts to the

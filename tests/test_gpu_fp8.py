@@ -209,6 +209,49 @@ def test_logits_track_the_fp8_emulation_and_the_fp32_forward(name, batch, flags,
     assert e_gpu32 <= 0.25                            # sanity bound in the max-norm
 
 
+def test_massive_activation_switches_the_fp8_context_to_the_stand_alone_layernorm():
+    """The folded fp8 path feeds the RAW residual rows to q|k|v and fc1 as e4m3, which saturates at 448.  One channel at
+    about 2 000 (the "massive activations" of trained ViTs, driven through the position embedding as in test_gpu_vit's
+    fp16 case) would be clipped in the operand.  The guard's second word tracks max |x|: the calibration forward at weight
+    load sees it and leaves the context on the stand-alone LayerNorm, whose NORMALISED operand fits e4m3 -- the device is
+    then as close to fp32 as the oracle's emulation of that data flow; forced to stay folded it is far off."""
+    cfg = S.CONFIGS["vit_base"]
+    t = S.make_tensors(cfg, 0)
+    t["pos"] = t["pos"].copy()
+    t["pos"][..., 301] += np.float32(2000.0)
+    blob = S.pack_blob(cfg, t)
+    images = S.make_images(cfg, 1, 4)
+    ref32 = O.vit_forward(cfg, blob, images)
+    emu = O.vit_forward(cfg, blob, images, fp8=True)                  # stand-alone LayerNorm data flow
+    rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=4)
+    assert ctx.ln_fold()
+    ctx.load_weights(blob)
+    amax, lim = ctx.fp8_guard()
+    _, _, tripped = ctx.ln_guard()
+    assert lim == 448.0 and amax > 1500.0 and tripped and not ctx.ln_fold(), (amax, lim, tripped)
+    d_in, d_out = vithip.DeviceBuffer.from_numpy(images), vithip.DeviceBuffer(4 * cfg["classes"] * 4)
+    ctx.forward_device_async(d_in.ptr, 4, d_out.ptr, steps=1)        # first call of the asynchronous entry point
+    ctx.synchronize()
+    got = d_out.to_numpy(np.float32, (4, cfg["classes"]))
+    ctx.close()
+    forced = vithip.VitContext(cfg, dtype=FP8, max_batch=4, flags=vithip.FLAG_LN_FOLD_ON)
+    forced.load_weights(blob)
+    clipped = forced.forward(images)
+    forced.close()
+    r_emu32, r_gpu32, r_clip32 = rms(emu, ref32), rms(got, ref32), rms(clipped, ref32)
+    print(f"\n[fp8 massive] channel at ~2000: max|x| bound {amax:.0f}; rms emu-fp32 {r_emu32:.3e} gpu-fp32 {r_gpu32:.3e}; "
+          f"forced fold (operand clipped at 448) {r_clip32:.3e}")
+    assert np.isfinite(got).all()
+    assert r_gpu32 <= 1.5 * r_emu32 + 1e-3
+    # the synthetic nets stay folded: their rows are O(1)
+    ok = vithip.VitContext(cfg, dtype=FP8, max_batch=1)
+    ok.load_weights(S.make_blob(cfg, 0))
+    a2, _ = ok.fp8_guard()
+    assert ok.ln_fold() and 0.0 < a2 < 448.0, a2
+    ok.close()
+
+
 def test_full_size_config_5_vit_base_fp8_batch_512_properties():
     # BASELINE.json config 5 at its FULL size: ViT-B/16, e4m3 GEMM operands, 512 images.  fp8 is outside the north
     # star's tolerance by construction, so the parity statement is the one of the small fp8 cases (the GPU follows the

@@ -436,24 +436,33 @@ hipError_t launch_mlp_update(float* w, float* b, const float* d, const float* x,
 // ---- folded LayerNorm: row statistics and weight folding -------------------------------------------------------
 // (the GEMM epilogues LNFOLD / RESID_LN of gemm_epilogue.h are the other half)
 
+__device__ __forceinline__ void ln_guard_update(float ratio, unsigned int* guard);
 // x fp32 [rows, dim] -> plain 16-bit cast + (mean, rstd) per row; one wave per row, like layernorm_kernel.
 // Used once per forward (first layer: its input comes from the patch embedding, not from a RESID_LN epilogue).
+// `amax_guard` (e4m3 rows only, optional): running maximum of |x| over the first `guard_rows` rows -- the raw rows are the
+// q|k|v / fc1 operand of the folded fp8 path and e4m3 saturates at 448 (vithip_api.hip, the guard's second word).
 template <typename T, int CH>
 __global__ void __launch_bounds__(256)
 rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float eps, typename T::elem* __restrict__ x16,
-                     float* __restrict__ stats, void* __restrict__ xlo_) {   // xlo != NULL: the split residual's lo plane (16-bit T: one byte per element; T = e4m3: bf16)
+                     float* __restrict__ stats, void* __restrict__ xlo_,   // xlo != NULL: the split residual's lo plane (16-bit T: one byte per element; T = e4m3: bf16)
+                     int64_t guard_rows, unsigned int* __restrict__ amax_guard) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nchunk = dim >> 2;
     const f32x4* xr = (const f32x4*)(x + row * dim);
     f32x4 v[CH];
-    float sum = 0.f;
+    float sum = 0.f, amax = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int c = lane + 64 * i;
         v[i] = c < nchunk ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        if constexpr (std::is_same<T, E4M3>::value)
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i][0]), fabsf(v[i][1]))), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
+    }
+    if constexpr (std::is_same<T, E4M3>::value) {
+        if (amax_guard) ln_guard_update(row < guard_rows ? amax : 0.f, amax_guard);   // whole wave = one row: uniform
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -488,30 +497,31 @@ rowstats_cast_kernel(const float* __restrict__ x, int64_t rows, int dim, float e
 }
 
 template <typename T>
-static hipError_t rowstats_t(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, hipStream_t s, void* xlo = nullptr) {
+static hipError_t rowstats_t(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, hipStream_t s, void* xlo = nullptr,
+                             int64_t guard_rows = 0, unsigned int* amax_guard = nullptr) {
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     auto o = (typename T::elem*)x16;
     void* const lo = xlo;
-    if (dim <= 256) hipLaunchKernelGGL((rowstats_cast_kernel<T, 1>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
-    else if (dim <= 512) hipLaunchKernelGGL((rowstats_cast_kernel<T, 2>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
-    else if (dim <= 768) hipLaunchKernelGGL((rowstats_cast_kernel<T, 3>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
-    else if (dim <= 1024) hipLaunchKernelGGL((rowstats_cast_kernel<T, 4>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
-    else if (dim <= 2048) hipLaunchKernelGGL((rowstats_cast_kernel<T, 8>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo);
+    if (dim <= 256) hipLaunchKernelGGL((rowstats_cast_kernel<T, 1>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo, guard_rows, amax_guard);
+    else if (dim <= 512) hipLaunchKernelGGL((rowstats_cast_kernel<T, 2>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo, guard_rows, amax_guard);
+    else if (dim <= 768) hipLaunchKernelGGL((rowstats_cast_kernel<T, 3>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo, guard_rows, amax_guard);
+    else if (dim <= 1024) hipLaunchKernelGGL((rowstats_cast_kernel<T, 4>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo, guard_rows, amax_guard);
+    else if (dim <= 2048) hipLaunchKernelGGL((rowstats_cast_kernel<T, 8>), grid, block, 0, s, x, rows, dim, eps, o, stats, lo, guard_rows, amax_guard);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 hipError_t launch_rowstats_cast(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, int dtype,
-                                hipStream_t s) {
+                                hipStream_t s, int64_t guard_rows, unsigned int* amax_guard) {
     if (rows <= 0 || dim <= 0 || (dim & 3)) return hipErrorInvalidValue;
-    if (dtype == VH_DTYPE_FP8) return rowstats_t<E4M3>(x, rows, dim, eps, x16, stats, s);   // e4m3 copy of the raw rows (fp8 path, folded LN)
+    if (dtype == VH_DTYPE_FP8) return rowstats_t<E4M3>(x, rows, dim, eps, x16, stats, s, nullptr, guard_rows, amax_guard);   // e4m3 copy of the raw rows (fp8 path, folded LN)
     return dtype == VH_DTYPE_BF16 ? rowstats_t<BF16>(x, rows, dim, eps, x16, stats, s)
                                   : rowstats_t<FP16>(x, rows, dim, eps, x16, stats, s);
 }
 
 hipError_t launch_rowstats_split(const float* x, int64_t rows, int dim, float eps, void* hi, void* lo, float* stats, int dtype,
-                                 hipStream_t s) {
+                                 hipStream_t s, int64_t guard_rows, unsigned int* amax_guard) {
     if (rows <= 0 || dim <= 0 || (dim & 3) || !lo) return hipErrorInvalidValue;
-    if (dtype == VH_DTYPE_FP8) return rowstats_t<E4M3>(x, rows, dim, eps, hi, stats, s, lo);   // e4m3 hi plane + bf16 lo plane
+    if (dtype == VH_DTYPE_FP8) return rowstats_t<E4M3>(x, rows, dim, eps, hi, stats, s, lo, guard_rows, amax_guard);   // e4m3 hi plane + bf16 lo plane
     return dtype == VH_DTYPE_BF16 ? rowstats_t<BF16>(x, rows, dim, eps, hi, stats, s, lo)
                                   : rowstats_t<FP16>(x, rows, dim, eps, hi, stats, s, lo);
 }
@@ -574,31 +584,36 @@ __device__ __forceinline__ void ln_guard_update(float ratio, unsigned int* guard
     for (int o = 32; o > 0; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)b, o); b = t > b ? t : b; }
     if ((threadIdx.x & 63) == 0 && b > __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(guard, b);
 }
+// `amax_guard` (optional; the fp8 path, whose folded operand is the RAW row as e4m3, saturating at 448): running maximum of an
+// upper bound of |x| over the real rows -- the square root of the largest 64-column block's sum of squares (>= the block's
+// largest element, <= 8 x its rms: it overshoots only where a block already carries several large elements).
 __global__ void __launch_bounds__(256)
 finalize_stats_kernel(const float* __restrict__ partials, int nblk, int64_t rows, int dim, float eps, float* __restrict__ stats,
-                      int64_t guard_rows, unsigned int* __restrict__ guard) {
+                      int64_t guard_rows, unsigned int* __restrict__ guard, unsigned int* __restrict__ amax_guard) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float ratio = 0.f;
+    float ratio = 0.f, bound = 0.f;
     if (r < rows) {
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, b2 = 0.f;
         for (int b = 0; b < nblk; ++b) {
             const float2 p = *(const float2*)(partials + 2 * ((int64_t)b * rows + r));
             s1 += p.x;
             s2 += p.y;
+            b2 = fmaxf(b2, p.y);
         }
         const float mean = s1 / (float)dim;
         const float var = fmaxf(s2 / (float)dim - mean * mean, 0.f);
         const float rstd = 1.0f / sqrtf(var + eps);
         *(float2*)(stats + 2 * r) = make_float2(mean, rstd);
-        if (r < guard_rows) ratio = fabsf(mean) * rstd;
+        if (r < guard_rows) { ratio = fabsf(mean) * rstd; bound = sqrtf(b2); }
     }
     if (guard) ln_guard_update(ratio, guard);   // (whole waves reach this: no early return above)
+    if (amax_guard) ln_guard_update(bound, amax_guard);
 }
 hipError_t launch_finalize_stats(const float* partials, int nblk, int64_t rows, int dim, float eps, float* stats, hipStream_t s,
-                                 int64_t guard_rows, unsigned int* guard) {
+                                 int64_t guard_rows, unsigned int* guard, unsigned int* amax_guard) {
     if (rows <= 0 || nblk <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, partials, nblk, rows, dim, eps, stats,
-                       guard_rows, guard);
+                       guard_rows, guard, amax_guard);
     return hipGetLastError();
 }
 // the same check on statistics that already exist (layer 0: written by the rowstats kernels)

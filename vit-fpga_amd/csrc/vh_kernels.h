@@ -90,16 +90,19 @@ hipError_t launch_pack_qkv(const float* qw, const float* qb, const float* kw, co
 hipError_t launch_permute_patch(const float* w_nchw, int dim, int channels, int patch, void* w16,
                                 int dtype, hipStream_t stream);
 // folded LayerNorm helpers
+// amax_guard (optional, e4m3 rows only): running maximum of |x| over the first guard_rows rows, as float bits
 hipError_t launch_rowstats_cast(const float* x, int64_t rows, int dim, float eps, void* x16, float* stats, int dtype,
-                                hipStream_t stream);
+                                hipStream_t stream, int64_t guard_rows = 0, unsigned int* amax_guard = nullptr);
 // guard (optional): running maximum of |mean| * rstd over the first `guard_rows` rows, as float bits (kernels_misc.hip)
+// amax_guard (optional): running maximum of an upper bound of |x| (largest 64-column block's root sum of squares)
 hipError_t launch_finalize_stats(const float* partials, int nblk, int64_t rows, int dim, float eps, float* stats,
-                                 hipStream_t stream, int64_t guard_rows = 0, unsigned int* guard = nullptr);
+                                 hipStream_t stream, int64_t guard_rows = 0, unsigned int* guard = nullptr,
+                                 unsigned int* amax_guard = nullptr);
 hipError_t launch_ln_guard(const float* stats, int64_t rows, unsigned int* guard, hipStream_t stream);
 // split residual (x = hi + lo, two 16-bit planes; gemm_epilogue.h RESID_SPLIT): fp32 rows -> planes + row statistics, and
 // the fp32 LayerNorm of selected rows (the CLS rows) of the planes
 hipError_t launch_rowstats_split(const float* x, int64_t rows, int dim, float eps, void* hi, void* lo, float* stats, int dtype,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int64_t guard_rows = 0, unsigned int* amax_guard = nullptr);
 hipError_t launch_layernorm_split(const void* hi, const void* lo, int64_t rows, int dim, int64_t row_stride, const float* gamma,
                                   const float* beta, float eps, float* out32, int dtype, hipStream_t stream);
 // fp8 path: the folded weights as e4m3 rows + scales (wscale), c = wscale * sum of the decoded row, d as launch_fold_ln

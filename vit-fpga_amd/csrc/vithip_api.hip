@@ -361,13 +361,18 @@ int prepare_weights(vh_ctx* c) {
 }
 
 // new weights: the guard starts over and the path is the configured one again
+void drop_graphs(vh_ctx* c);
 int guard_reset(vh_ctx* c) {
-    HIPCHK(&c->err, hipStreamSynchronize(c->stream));   // no forward in flight still writes the word
-    HIPCHK(&c->err, hipMemsetAsync(c->guard_dev, 0, sizeof(unsigned int), c->stream));
-    *c->guard_host = 0.f;
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));   // no forward in flight still writes the words
+    HIPCHK(&c->err, hipMemsetAsync(c->guard_dev, 0, 2 * sizeof(unsigned int), c->stream));
+    c->guard_host[0] = c->guard_host[1] = 0.f;
     c->guard_tripped = false;
     c->ln_fold = c->ln_fold_cfg;
     c->split = c->split_cfg;
+    // Captured launch sequences belong to the path (and the weight layout) they were captured on: a context whose guard had
+    // tripped holds graphs of the stand-alone-LayerNorm sequence, and replaying those against re-folded weights would be
+    // silently wrong.  New weights, new graphs.
+    drop_graphs(c);
     return VH_OK;
 }
 
@@ -418,6 +423,9 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     // launch is a 5 us fill kernel in front of every attention kernel)
     unsigned int* const tickets_part = c->tickets + (size_t)img0 * (f.layers > 0 ? f.layers : 1);
     if (f.layers > 0) HIPCHK(&c->err, hipMemsetAsync(tickets_part, 0, sizeof(unsigned int) * f.layers, s));
+    // fp8 operands: the folded GEMMs multiply the RAW residual rows as e4m3, which saturates at 448 -- the statistics kernels
+    // keep a running maximum of |x| (a bound of it) in the guard's second word
+    unsigned int* const amax_guard = c->fp8 ? c->guard_dev + 1 : nullptr;
     auto mark = [&](int stage) -> int {
         if (!ev) return VH_OK;
         hipEvent_t e;
@@ -469,7 +477,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = mark(ST_PATCH))) return rc;
         HIPCHK(&c->err, launch_cls_rows_split(xn16, xlo16, partials_p, rows_g, P + L.cls, P + L.pos, batch, T, D, dt16, s));
         if ((rc = mark(ST_CLS))) return rc;
-        HIPCHK(&c->err, launch_finalize_stats(partials_p, D / 64, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev));
+        HIPCHK(&c->err, launch_finalize_stats(partials_p, D / 64, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev, amax_guard));
         if ((rc = mark(ST_LNSTATS))) return rc;
     } else {
         HIPCHK(&c->err, gemm(col16, c->wp16, P + L.patch_b, x, (int64_t)batch * L.NP, D, L.KP, VH_EPI_PATCH, P + L.pos, L.NP));
@@ -479,8 +487,8 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if (c->ln_fold && nl > 0) {
             // layer 0's LN1 statistics: its input comes from the patch embedding, not from a RESID_LN epilogue
             // (fp8 path with the split residual: the patch embedding stays the bf16 fp32-out GEMM; this pass makes the planes)
-            if (c->split) HIPCHK(&c->err, launch_rowstats_split(x, rows_g, D, f.ln_eps, xn16, xlo16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s));
-            else HIPCHK(&c->err, launch_rowstats_cast(x, rows_g, D, f.ln_eps, xn16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s));
+            if (c->split) HIPCHK(&c->err, launch_rowstats_split(x, rows_g, D, f.ln_eps, xn16, xlo16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s, rows, amax_guard));
+            else HIPCHK(&c->err, launch_rowstats_cast(x, rows_g, D, f.ln_eps, xn16, stats_p, c->fp8 ? VH_DTYPE_FP8 : dt16, s, rows, amax_guard));
             HIPCHK(&c->err, launch_ln_guard(stats_p, rows, c->guard_dev, s));   // real rows only (rows_g - rows are tile padding)
             if ((rc = mark(ST_LNSTATS))) return rc;
         }
@@ -539,7 +547,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         else HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows_g, D, D, VH_EPI_RESID_LN, nullptr, 0, so));
         if ((rc = tmark(ST_PROJ))) return rc;
         if ((rc = mark(ST_PROJ))) return rc;
-        HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev));
+        HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev, amax_guard));
         if ((rc = mark(ST_LNSTATS))) return rc;
         if ((rc = tmark(ST_FC1))) return rc;
         HIPCHK(&c->err, gemm(xn16, c->w1_16[l], cd + 6 * D + M, h16, rows_g, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0, s1));
@@ -551,7 +559,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_FC2))) return rc;
         if ((rc = mark(ST_FC2))) return rc;
         if (l + 1 < nl) {
-            HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev));
+            HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev, amax_guard));
             if ((rc = mark(ST_LNSTATS))) return rc;
         }
     }
@@ -650,12 +658,16 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
 
 // end of a forward: the guard word travels to pinned host memory behind the forward's kernels (stream order)
 int guard_publish(vh_ctx* c) {
-    if (c->ln_fold) HIPCHK(&c->err, hipMemcpyAsync(c->guard_host, c->guard_dev, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (c->ln_fold) HIPCHK(&c->err, hipMemcpyAsync(c->guard_host, c->guard_dev, 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     return VH_OK;
 }
 // top of every forward entry point: has a COMPLETED forward seen rows beyond the guard's threshold?  (NaN trips it too.)
+// Second word, fp8 operands only: rows whose raw values leave e4m3's range (the folded operand would clip them).
+constexpr float kE4M3Max = 448.f;
 bool guard_exceeded(const vh_ctx* c) {
-    return c->ln_fold && c->guard_host && !(*(volatile const float*)c->guard_host <= c->guard_thresh);
+    if (!c->ln_fold || !c->guard_host) return false;
+    const volatile float* g = c->guard_host;
+    return !(g[0] <= c->guard_thresh) || (c->fp8 && !(g[1] <= kE4M3Max));
 }
 int prepare_weights(vh_ctx* c);
 void drop_graphs(vh_ctx* c);
@@ -738,6 +750,26 @@ int run_step(vh_ctx* c, const float* in, int batch, float* logits) {
     HIPCHK(&c->err, hipGraphLaunch(g.exec, c->stream));
     c->last_batch = batch;
     return VH_OK;
+}
+
+// Weight-load time: decide the guarded fold BEFORE the first caller's forward.  A checkpoint's common-mode offset (position
+// embedding, biases) and its massive activations are properties of the weights far more than of the image, so ONE seeded
+// calibration image through the freshly prepared folded path measures them; if the guard trips, the context switches to
+// the stand-alone LayerNorm here, and the asynchronous entry points (vh_forward_device_async, the ring, the groups) never
+// return a batch computed on a tripped fold because of the WEIGHTS.  The per-forward guard stays as the backstop for what
+// only the data can cause.  ~1.5 ms per weight load (a batch-1 forward).
+int guard_calibrate(vh_ctx* c) {
+    if (!c->guard_auto || !c->ln_fold) return VH_OK;
+    const vh_config& f = c->cfg;
+    const int64_t n = (int64_t)f.image_size * f.image_size * f.channels;
+    HIPCHK(&c->err, launch_fill(c->in_dev, n, 0xCA11B8A7Eull, TID_IMAGES, 0, 0.f, 0.f, c->stream));
+    const int keep_stage = c->timing_stage;
+    c->timing_stage = -1;
+    const int rc = enqueue_step(c, c->in_dev, 1, c->logits_dev);
+    c->timing_stage = keep_stage;
+    if (rc) return rc;
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    return guard_poll(c);
 }
 
 int check_forward_args(vh_ctx* c, const void* in, int batch, const void* out) {
@@ -989,12 +1021,23 @@ int vh_get_ln_guard(vh_ctx* c, float* max_ratio, float* threshold, int* tripped)
     if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
     HIPCHK(&c->err, hipSetDevice(c->device));
     HIPCHK(&c->err, hipStreamSynchronize(c->stream));
-    float seen = 0.f;
-    HIPCHK(&c->err, hipMemcpy(&seen, c->guard_dev, sizeof seen, hipMemcpyDeviceToHost));
-    if (!(seen <= c->guard_thresh) && c->ln_fold_cfg) c->guard_tripped = true;
-    if (max_ratio) *max_ratio = seen;
+    float seen[2] = {0.f, 0.f};
+    HIPCHK(&c->err, hipMemcpy(seen, c->guard_dev, sizeof seen, hipMemcpyDeviceToHost));
+    if ((!(seen[0] <= c->guard_thresh) || (c->fp8 && !(seen[1] <= kE4M3Max))) && c->ln_fold_cfg) c->guard_tripped = true;
+    if (max_ratio) *max_ratio = seen[0];
     if (threshold) *threshold = c->guard_thresh;
     if (tripped) *tripped = c->guard_tripped ? 1 : 0;
+    return VH_OK;
+}
+
+int vh_get_fp8_guard(vh_ctx* c, float* max_abs, float* limit) {
+    if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
+    HIPCHK(&c->err, hipSetDevice(c->device));
+    HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    float seen[2] = {0.f, 0.f};
+    HIPCHK(&c->err, hipMemcpy(seen, c->guard_dev, sizeof seen, hipMemcpyDeviceToHost));
+    if (max_abs) *max_abs = c->fp8 ? seen[1] : 0.f;
+    if (limit) *limit = kE4M3Max;
     return VH_OK;
 }
 
@@ -1010,7 +1053,8 @@ int vh_load_weights(vh_ctx* c, const void* host_blob, size_t nbytes) {
     c->weights_ready = false;
     HIPCHK(&c->err, hipMemcpyAsync(c->blob, host_blob, nbytes, hipMemcpyHostToDevice, c->stream));
     if ((rc = guard_reset(c))) return rc;
-    return prepare_weights(c);
+    if ((rc = prepare_weights(c))) return rc;
+    return guard_calibrate(c);
 }
 
 int vh_load_weights_device(vh_ctx* c, const void* dev_blob, size_t nbytes) {
@@ -1025,7 +1069,8 @@ int vh_load_weights_device(vh_ctx* c, const void* dev_blob, size_t nbytes) {
     c->weights_ready = false;
     if (dev_blob != c->blob) HIPCHK(&c->err, hipMemcpyAsync(c->blob, dev_blob, nbytes, hipMemcpyDeviceToDevice, c->stream));
     if ((rc = guard_reset(c))) return rc;
-    return prepare_weights(c);
+    if ((rc = prepare_weights(c))) return rc;
+    return guard_calibrate(c);
 }
 
 int vh_init_weights_seeded(vh_ctx* c, uint64_t seed) {
@@ -1065,7 +1110,8 @@ int vh_init_weights_seeded(vh_ctx* c, uint64_t seed) {
     GEN(L.headw, C * D, TID_FINAL + 2, sw, 0.f); GEN(L.headb, C, TID_FINAL + 3, sb, 0.f);
 #undef GEN
     if (int rc = guard_reset(c)) return rc;
-    return prepare_weights(c);
+    if (int rc = prepare_weights(c)) return rc;
+    return guard_calibrate(c);
 }
 
 int vh_export_weights(vh_ctx* c, void* host_blob, size_t nbytes) {
@@ -1223,6 +1269,9 @@ int vh_synchronize(vh_ctx* c) {
     if (!c) return fail(nullptr, VH_ERR_INVALID, "null context");
     HIPCHK(&c->err, hipSetDevice(c->device));
     HIPCHK(&c->err, hipStreamSynchronize(c->stream));
+    // everything enqueued has completed: if one of those forwards tripped the fold's guard, switch NOW rather than at the
+    // next forward's entry (vh_get_ln_guard reports it; the results already delivered came from the folded path)
+    if (c->weights_ready) return guard_poll(c);
     return VH_OK;
 }
 

@@ -53,6 +53,7 @@ SYMBOLS = {
     "vh_get_config": (_i, [_vp, C.POINTER(Config)]),
     "vh_get_ln_fold": (_i, [_vp, _pi]),
     "vh_get_ln_guard": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), _pi]),
+    "vh_get_fp8_guard": (_i, [_vp, C.POINTER(_f), C.POINTER(_f)]),
     "vh_weight_blob_bytes": (_sz, [C.POINTER(Config)]),
     "vh_load_weights": (_i, [_vp, _vp, _sz]),
     "vh_load_weights_device": (_i, [_vp, _vp, _sz]),
@@ -318,6 +319,12 @@ class VitContext:
         _check(lib().vh_get_ln_guard(self.h, C.byref(r), C.byref(t), C.byref(trip)), self.h)
         return r.value, t.value, bool(trip.value)
 
+    def fp8_guard(self):
+        """(largest |x| bound seen on the raw residual rows of an fp8 context, e4m3's limit 448)."""
+        a, lim = C.c_float(0), C.c_float(0)
+        _check(lib().vh_get_fp8_guard(self.h, C.byref(a), C.byref(lim)), self.h)
+        return a.value, lim.value
+
     def load_weights(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         _check(lib().vh_load_weights(self.h, blob.ctypes.data, blob.nbytes), self.h)
@@ -490,6 +497,12 @@ class VitGroup:
         n = C.c_int(0)
         self._chk(lib().vh_group_size(self.h, C.byref(n)))
         return n.value
+
+    def fp8_guard(self):
+        """(largest |x| bound seen on the raw residual rows of an fp8 context, e4m3's limit 448)."""
+        a, lim = C.c_float(0), C.c_float(0)
+        _check(lib().vh_get_fp8_guard(self.h, C.byref(a), C.byref(lim)), self.h)
+        return a.value, lim.value
 
     def load_weights(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
