@@ -384,7 +384,11 @@ def main_group(args):
     B = args.batch
     n = args.gpus
     dt = {"bf16": vithip.DTYPE_BF16, "fp16": vithip.DTYPE_FP16, "fp8": vithip.DTYPE_FP8}[args.dtype]
-    grp = vithip.VitGroup(cfg, list(range(n)), dtype=dt, max_batch_per_device=B)
+    # --same-device: a REHEARSAL group -- device 0 listed n times: the N > 1 control flow of vh_group_* (n host threads, the
+    # device-blob hand-over, shard bounds, concurrent member forwards) on a one-GPU box.  The members share one GPU, so the
+    # rate says nothing about scaling: the line is labelled and carries no `value`.
+    rehearsal = bool(args.same_device)
+    grp = vithip.VitGroup(cfg, [0] * n if rehearsal else list(range(n)), dtype=dt, max_batch_per_device=B)
     grp.init_weights_seeded(0)            # device 0 generates, the blob is broadcast to the others
     grp.fill_inputs_seeded(1, B)          # every device its own shard, generated in HBM
     if args.warmup > 0:
@@ -410,6 +414,28 @@ def main_group(args):
            "forward_mfma_frac": round(ips / n * flops_img / (PEAK_TFLOPS[args.dtype] * 1e12), 4), "roofline": None}
     if not args.no_parity:
         out["parity"] = parity_of(cfg, logits[:B], min(args.parity_images, B), args.dtype, 1, np, S)
+    if rehearsal:
+        # every member's shard against a plain context on the same seeded images: sharded == unsharded, bit for bit
+        ctx = vithip.VitContext(cfg, dtype=dt, max_batch=B)
+        ctx.init_weights_seeded(0)
+        px = cfg["image_size"] ** 2 * cfg["channels"]
+        din, dout = vithip.DeviceBuffer(B * px * 4), vithip.DeviceBuffer(B * cfg["classes"] * 4)
+        same = True
+        for i in range(n):
+            ctx.fill_input_seeded(1 + i, B, din.ptr)
+            ctx.forward_device(din.ptr, B, dout.ptr)
+            same &= bool(np.array_equal(dout.to_numpy(np.float32, (B, cfg["classes"])), logits[i * B:(i + 1) * B]))
+        ctx.close()
+        out["rehearsal"] = {"members_on_device_0": n, "images_per_s_all_members_sharing_one_gpu": out["value"],
+                            "sharded_equals_unsharded_bitwise": same,
+                            "note": "REHEARSAL of the vh_group_* control flow on ONE GPU (device 0 listed n times; the weight "
+                                    "broadcast is a device-to-device copy, RCCL cannot hold one device twice): NOT a scaling "
+                                    "measurement, no N > 1 run exists (DESIGN.md section 8)"}
+        out["value"] = None
+        out["forward_mfma_frac"] = None
+        if not same:
+            print(json.dumps(out), flush=True)
+            raise SystemExit("rehearsal group: sharded logits differ from the plain context's")
     print(json.dumps(out), flush=True)
     grp.close()
 

@@ -36,6 +36,33 @@ def test_group_forward_equals_one_context_bitwise(devices):
     g.close()
 
 
+def test_rehearsal_group_of_eight_members_shards_batch_512_bitwise():
+    """The driver's 8-GPU shape rehearsed on one GPU: eight members (device 0 eight times -- eight host threads, eight
+    contexts, eight device-blob hand-overs), ViT-B/16, batch 8 x 64 = 512 images given as ONE host batch; the group's
+    logits equal the unsharded batch-512 forward of one context bit for bit.  (No N > 1 run on distinct GPUs exists.)"""
+    cfg = S.CONFIGS["vit_base"]
+    n, per = 8, 64
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_BF16, max_batch=n * per)
+    ctx.init_weights_seeded(0)
+    blob = ctx.export_weights()
+    px = cfg["image_size"] ** 2 * cfg["channels"]
+    din, dout = vithip.DeviceBuffer(n * per * px * 4), vithip.DeviceBuffer(n * per * cfg["classes"] * 4)
+    ctx.fill_input_seeded(1, n * per, din.ptr)
+    ctx.forward_device(din.ptr, n * per, dout.ptr)
+    want = dout.to_numpy(np.float32, (n * per, cfg["classes"]))
+    images = din.to_numpy(np.float32, (n * per, cfg["image_size"], cfg["image_size"], cfg["channels"]))
+    ctx.close()
+    g = vithip.VitGroup(cfg, [0] * n, dtype=vithip.DTYPE_BF16, max_batch_per_device=per)
+    assert g.size() == n
+    g.load_weights(blob)
+    got = g.forward(images)
+    for r in range(n):                       # the shard bounds the group used
+        lo, hi = vithip.group_shard_bounds(n * per, n, r)
+        assert (lo, hi) == (r * per, (r + 1) * per)
+    g.close()
+    assert np.isfinite(want).all() and np.array_equal(got, want)
+
+
 def test_group_seeded_weights_and_resident_path():
     cfg = S.CONFIGS["vit_tiny"]
     B = 3

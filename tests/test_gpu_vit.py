@@ -73,6 +73,25 @@ def test_vit_large_384_long_sequence_config():
     ctx.close()
 
 
+def test_vit_large_384_fp16_is_inside_the_north_star_tolerance_on_16_images():
+    """BASELINE config 4's parity claim on a sample that can show its margin: ViT-L/16 at 384x384, fp16, 16 images, default
+    flags (the guarded fold, the two-plane residual with the one-byte lo plane); the WORST image must be inside 1e-3.
+    24 layers leave less room than ViT-B's 12 (measured 9.2e-4 worst / 8.0e-4 median on these 16 images, profiles/r04_*): the
+    fp32-residual build of the same tree measures the same (9.3e-4), so what is left is the 16-bit operand format, not the planes."""
+    cfg = S.CONFIGS["vit_large_384"]
+    n = 16
+    blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, n)
+    ref = O.vit_forward(cfg, blob, images)
+    ctx = vithip.VitContext(cfg, dtype=vithip.DTYPE_FP16, max_batch=n)
+    ctx.load_weights(blob)
+    assert ctx.ln_fold()
+    got = ctx.forward(images)
+    ctx.close()
+    per = np.abs(got - ref).max(1) / np.abs(ref).max()
+    print(f"\n[parity] vit_large_384 fp16 {n} images, default flags: worst {per.max():.3e} median {np.median(per):.3e}")
+    assert np.isfinite(got).all() and per.max() <= NORTH_STAR, per.max()
+
+
 @pytest.mark.parametrize("flags,label", [(vithip.FLAG_LN_FOLD_ON, "folded"), (vithip.FLAG_LN_FOLD_OFF, "stand-alone")])
 def test_fp16_is_inside_the_north_star_tolerance_on_64_vit_b_images(flags, label):
     """The configuration that carries the parity claim: ViT-B/16, fp16 operands, 64 images, BOTH LayerNorm paths; the worst
@@ -190,7 +209,7 @@ def test_the_per_forward_guard_is_the_backstop_for_what_only_the_data_can_cause(
     the fold; the first batch of DC images trips the guard; vh_synchronize (or the next forward entry) switches the context."""
     cfg = S.CONFIGS["vit_base"]
     t = S.make_tensors(cfg, 0)
-    t["patch.weight"] = t["patch.weight"] + np.float32(0.004)
+    t["patch.weight"] = t["patch.weight"] + np.float32(0.0015)
     blob = S.pack_blob(cfg, t)
     images = (S.make_images(cfg, 1, 2) * np.float32(0.1) + np.float32(0.9)).astype(np.float32)
     ref = O.vit_forward(cfg, blob, images)

@@ -440,7 +440,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
     // QS: outstanding operations a wait may leave behind (see the table above)
     // NST = output store instructions per wave and item: 4 x 16 bytes per lane for 16-bit results (the widened form at the
     // item end), 8 x 4 bytes for e4m3.  Every "8" of the table above is NST here.
-    constexpr int NST = sizeof(typename TO::elem) == 2 ? 4 : 8;
+    constexpr int NST = 4;   // (16-bit results: 4 x 16 bytes per lane; e4m3: 4 x 8 bytes)
     const int w_top = 2 * (ntiles - 2) + NST, w_t1 = 2 * (ntiles - 3) + NST + 2, w_mid = 2 * ntiles + nw - 4 + NST, w_last = nw + 2 + 2 * (ntiles - 3);
     bool stored = false;   // did this wave issue the NST stores of the previous item (wave-uniform)
 
@@ -498,7 +498,16 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
         }
         if (!(VH_ATTN_ABL & 2) && !first && slab == 0 && wave < 4) issue_tile(cbase, ntiles - 1);   // (a later slab finds the whole image in place)
         if (QS) {   // this wave's Q fragments out of the staging area (free again after the barrier at the top of tile 1)
-            const int qa = q_off + wave * 4096 + k0;
+            int qa = q_off + wave * 4096 + k0;
+            if constexpr (!std::is_same<T, TO>::value) {
+                // e4m3 results: one register short at 128 -- the four lane-constant addresses below were hoisted out of the item
+                // loop and SPILLED, and their reloads (vector-memory operations) made every item top wait for vmcnt(0).
+                // Recomputed from a laundered lane id per item instead (3 VALU operations).
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int r31 = ln & 31;
+                qa = q_off + wave * 4096 + r31 * 128 + ((((ln >> 5)) ^ ((r31 >> 1) & 7)) << 4);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const vec8*)(smem + (qa ^ (ks << 5)));
         }
@@ -512,7 +521,10 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
         // S^T tile: 32 keys x 32 queries, accumulators start at `init` (= -shift)
         auto qk = [&](int kt, float init) {
             // all four K fragments requested up front (hipcc, register-shy at this occupancy, otherwise reads one, waits, multiplies)
-            const int ka = k0 + kt * 4096;
+            int ka = k0 + kt * 4096;
+            // (e4m3 results: the three other chunk addresses are XORs of this one; kept opaque so that they are recomputed per
+            //  tile instead of being hoisted into three more registers this instantiation does not have)
+            if constexpr (!std::is_same<T, TO>::value) asm volatile("" : "+v"(ka));
             vec8 kf[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -680,12 +692,21 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
                         if (q < tokens) *(u32x4*)(op + 32 * db + 8 * rg) = u32x4{sx[0], sy[0], sx[1], sy[1]};
                     }
                 }
-            } else if (q < tokens) {
-                typename TO::elem* op = out + ((int64_t)b * tokens + q) * D + h * 64 + 4 * hl;
+            } else {
+                // e4m3 output (fp8 path): a lane's quad of a group is ONE dword; the same half exchange on a pair of groups
+                // leaves lanes 0-31 with the 8 bytes of group rg and lanes 32-63 with those of group rg + 1: 4 x 8 bytes per
+                // lane instead of 8 x 4 (round 4; NST follows)
+                typename TO::elem* const op = out + ((int64_t)b * tokens + (q < tokens ? q : tokens - 1)) * D + h * 64 + 8 * hl;
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    *(typename TO::vec4*)(op + 8 * rg) = pack4<TO>(o0[4 * rg] * inv, o0[4 * rg + 1] * inv, o0[4 * rg + 2] * inv, o0[4 * rg + 3] * inv);
-                    *(typename TO::vec4*)(op + 32 + 8 * rg) = pack4<TO>(o1[4 * rg] * inv, o1[4 * rg + 1] * inv, o1[4 * rg + 2] * inv, o1[4 * rg + 3] * inv);
+                for (int db = 0; db < 2; ++db) {
+                    const f32x16& o = db ? o1 : o0;
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg += 2) {
+                        const uint32_t ga = pack4<TO>(o[4 * rg] * inv, o[4 * rg + 1] * inv, o[4 * rg + 2] * inv, o[4 * rg + 3] * inv);
+                        const uint32_t gb = pack4<TO>(o[4 * rg + 4] * inv, o[4 * rg + 5] * inv, o[4 * rg + 6] * inv, o[4 * rg + 7] * inv);
+                        const auto sx = __builtin_amdgcn_permlane32_swap(ga, gb, false, false);
+                        if (q < tokens) *(u32x2*)(op + 32 * db + 8 * rg) = u32x2{sx[0], sx[1]};
+                    }
                 }
             }
         }
@@ -745,8 +766,6 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     // staged-Q ring (counted waits): one slab of at least four waves whose trimmed images + staging fit twice in a CU
     const int G = (tokens + 7) / 8, G2 = (G + 1) & ~1;
     const size_t qs_lds = (size_t)(G + G2 + 4 * nw) * 1024 + 16;   // + the ticket word
-    // (16-bit output only: the e4m3-output instantiation of the staged form does not fit 128 VGPRs without spilling)
-    if constexpr (std::is_same<T, TO>::value)
     if (want_ring >= 1 && want_ring != 2 && slabs == 1 && nw >= 4 && 2 * qs_lds <= 160 * 1024) {
         auto k = attention_ring_kernel<T, TO, true>;
         static LdsDone lds_done;
