@@ -150,7 +150,9 @@ def test_gemm_bf16_and_gelu_e4m3_outputs(M, N, K):
     assert np.isfinite(got8).all()
     step = np.maximum(np.abs(want8), 2.0 ** -6) * 2.0 ** -3 + 1e-12
     assert np.all(np.abs(got8 - want8) <= step * 1.001)
-    assert (got8 == want8).mean() >= 0.995, (got8 == want8).mean()
+    # (e4m3 results use the degree-6 GELU polynomial since round 4: |error| <= 5.7e-4, a quarter of e4m3's smallest step -- it
+    #  moves a value across a rounding boundary a little more often than fp32 summation order alone did: 0.995 before)
+    assert (got8 == want8).mean() >= 0.97, (got8 == want8).mean()
 
 
 def test_layernorm_and_attention_write_e4m3():

@@ -310,11 +310,12 @@ def test_attention_persistent_workgroups_walk_several_items(batch, tokens, heads
         assert per_image.max() <= ATT_TOL[dt], (what, int(per_image.argmax()), float(per_image.max()))
 
 
+@pytest.mark.parametrize("tokens", [197, 577])   # the staged ring; the multi-slab ring of the long sequences (round 4)
 @pytest.mark.parametrize("dt", DT)
-def test_attention_spiked_scores_force_rescale(dt):
+def test_attention_spiked_scores_force_rescale(dt, tokens):
     # one key row aligned with one query row far above the rest: the running max jumps in a late
     # tile, exercising the online-softmax rescale of O and l (rule: a rare branch needs its own test)
-    batch, tokens, heads = 1, 197, 1
+    batch, heads = 1, 1
     D = 64
     qkv = (S.fill(tokens * 3 * D, 11, 1, 0) * 0.5).reshape(tokens, 3 * D)
     qkv[5, :D] = 4.0

@@ -28,10 +28,15 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--tokens", type=int, default=0, help="operator tap only, on this sequence length instead of the model's")
     a = ap.parse_args()
     cfg = S.CONFIGS[a.config]
     D, H, T = cfg["dim"], cfg["heads"], S.tokens(cfg)
     dt = vithip.DTYPE_BF16 if a.dtype == "bf16" else vithip.DTYPE_FP16
+    if a.tokens:
+        T = a.tokens
+        tap(a, dt, D, H, T)
+        return
     byts = a.batch * T * 4 * D * 2
     # (1) device time per launch inside the forward: hip events on the context's stream around every attention launch
     ctx = vithip.VitContext(cfg, dtype=dt, max_batch=a.batch)
@@ -48,6 +53,10 @@ def main():
     ctx.close(); din.free(); dout.free()
     print(f"attention {a.config} b{a.batch} T={T} H={H} {a.dtype}, in the forward (hip events, {n} launches): "
           f"{avg_ms * 1e3:8.1f} us average, {min_ms * 1e3:8.1f} us min  {byts / (avg_ms * 1e3) / 1e6:6.2f} TB/s algorithmic", flush=True)
+    tap(a, dt, D, H, T)
+
+
+def tap(a, dt, D, H, T):
     # (2) the operator tap, timed from the host: every call allocates its work-queue counter, zeroes it, launches and
     # SYNCHRONISES -- 30-40 us of host work per call on top of the kernel.  Round 2 quoted this figure (178-188 us)
     # beside the kernel trace's 150 us; the difference is the tap, not the kernel.
@@ -67,7 +76,7 @@ def main():
         vithip.op_attention(qkv.ptr, a.batch, T, H, out.ptr, dt)
     drain()
     us = (time.perf_counter() - t0) / a.iters * 1e6
-    print(f"   the same launch through the synchronising operator tap, host clock: {us:8.1f} us per call (kernel + allocation, memset, "
+    print(f"   T={T} H={H} b{a.batch}: the launch through the synchronising operator tap, host clock: {us:8.1f} us per call (kernel + allocation, memset, "
           f"launch and a stream synchronisation per call)", flush=True)
 
 

@@ -73,40 +73,61 @@ __device__ __forceinline__ float gelu_fast(float v) {
     return fmaf(-u, h, fmaxf(v, 0.f));
 }
 
-// The same function for a quad of values, transcendental-free: Phi(v) - 1/2 = c*P(t) with c = clamp(v, -4.5, 4.5),
-// t = 2c^2/4.5^2 - 1 and P the degree-10 near-minimax fit (Chebyshev nodes) of (Phi(c) - 1/2)/c on [0, 4.5];
-// gelu(v) = v*(1/2 + c*P(t)).  |error| <= 1.8e-5 absolute for every v (3.6e-6 for |v| <= 3, the clamp's residue
-// 3.4e-6*|v| beyond 4.5): an order below the 16-bit rounding of the stored value.  Written on pairs so that every
-// step is one v_pk_{mul,fma}_f32: 7 packed ops + 1 v_med3 per value instead of 13 scalar ops of which two
-// (v_exp, v_rcp) issue at quarter rate -- the fc1 epilogue is VALU-bound on this.
+// The same function for a quad of values, transcendental-free and (round 4) without per-value clamps:
+//     w   = clamp01(1 - v^2 / 4.5^2)                (ONE packed fma with the instruction's clamp modifier: 0 beyond |v| = 4.5)
+//     R   = P(w), degree DEG                        (R = (Phi(v) - 1/2) / v on |v| <= 4.5, and its value at 4.5 beyond)
+//     Phi = clamp01(1/2 + v R)                      (again the modifier: beyond 4.5 the line 1/2 + v R(0) leaves [0, 1] and saturates)
+//     gelu(v) = v Phi
+// i.e. DEG + 4 packed operations per PAIR of values and nothing else (round 1's form: two v_med3 + 13 packed operations for degree
+// 10 in t = 2 c^2 / 4.5^2 - 1).  The fc1 epilogue is VALU-throughput-bound on exactly these instructions (DESIGN.md 4.1,
+// tools/probe_valu.hip: 3.3 cycles per packed fp32 instruction with two waves on the SIMD, whatever it computes).
+// P is a weighted least-squares / reweighted minimax fit of (Phi(c) - 1/2)/c on [0, 4.5] with the error weighted by c^2 (what
+// gelu = v (1/2 + v R) sees), written in powers of w: Horner in w has its rounding where v^2 is SMALL (w near 1) and is exact to
+// a few ulps where the weight is large (w near 0).  |gelu error|, fp32 Horner with fma, every v:
+//     DEG 9: 7.7e-6  (fp16 results; round 1's degree-10 fit in t: 1.8e-5)     DEG 8: 3.4e-5  (bf16 results: half a bf16 ulp of 0.017)
+//     DEG 6: 5.7e-4  (e4m3 results: a quarter of e4m3's smallest step)
+// (tools: the fit is reproduced by tools/gelu_fit.py.)  Beyond the clamp the result is v or 0 exactly (true value within 3.4e-6 |v|).
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <int DEG> struct GeluW;
+template <> struct GeluW<9> { static constexpr float a[10] = {1.111100093e-01f, 5.562581867e-02f, 3.875113651e-02f, 7.441916317e-02f, -2.459328771e-01f,
+                                                                1.095633626e+00f, -2.419960260e+00f, 3.303298712e+00f, -2.415727854e+00f, 8.016663194e-01f}; };
+template <> struct GeluW<8> { static constexpr float a[9] = {1.111119911e-01f, 5.524744466e-02f, 5.048053339e-02f, -6.402773410e-02f, 5.648611188e-01f,
+                                                               -1.549515009e+00f, 2.612281084e+00f, -2.240322828e+00f, 8.585962057e-01f}; };
+template <> struct GeluW<6> { static constexpr float a[7] = {1.111383960e-01f, 5.238987878e-02f, 9.770081192e-02f, -3.239865899e-01f, 1.061976552e+00f,
+                                                               -1.360716462e+00f, 7.577903271e-01f}; };
+// d = clamp01(a * b + c) on a pair: v_pk_fma_f32 with the clamp modifier (no builtin carries it; a NaN comes out as 0 under the
+// kernels' DX10_CLAMP mode, and the final v * Phi makes it a NaN again)
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 // the two pairs of a quad advance in step: a packed fp32 op feeding the next instruction costs a wait state,
 // two independent chains in alternation cost none
+template <int DEG>
 __device__ __forceinline__ f32x4 gelu_poly4(f32x4 v) {
-    f32x2 x[2] = {f32x2{v[0], v[1]}, f32x2{v[2], v[3]}}, c[2], t[2], p[2];
+    constexpr const float* a = GeluW<DEG>::a;
+    f32x2 x[2] = {f32x2{v[0], v[1]}, f32x2{v[2], v[3]}}, w[2], p[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        c[h][0] = __builtin_amdgcn_fmed3f(x[h][0], -4.5f, 4.5f);
-        c[h][1] = __builtin_amdgcn_fmed3f(x[h][1], -4.5f, 4.5f);
-    }
+    for (int h = 0; h < 2; ++h) w[h] = x[h] * x[h];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) t[h] = c[h] * c[h];
+    for (int h = 0; h < 2; ++h) w[h] = pk_fma_clamp01(w[h], f32x2{-4.938271605e-02f, -4.938271605e-02f}, f32x2{1.f, 1.f});
 #pragma unroll
-    for (int h = 0; h < 2; ++h) t[h] = __builtin_elementwise_fma(t[h], f32x2{9.876543210e-02f, 9.876543210e-02f}, f32x2{-1.f, -1.f});
+    for (int h = 0; h < 2; ++h) p[h] = __builtin_elementwise_fma(w[h], f32x2{a[DEG], a[DEG]}, f32x2{a[DEG - 1], a[DEG - 1]});
 #pragma unroll
-    for (int h = 0; h < 2; ++h) p[h] = __builtin_elementwise_fma(t[h], f32x2{9.806926011e-04f, 9.806926011e-04f}, f32x2{-2.340015935e-03f, -2.340015935e-03f});
-    constexpr float kc[9] = {2.716277400e-03f, -5.251548121e-03f, 1.143922652e-02f, -1.902094059e-02f, 2.828393083e-02f,
-                             -4.010921159e-02f, 5.470119065e-02f, -7.719386095e-02f, 1.569049305e-01f};
+    for (int k = DEG - 2; k >= 0; --k)
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+        for (int h = 0; h < 2; ++h) p[h] = __builtin_elementwise_fma(p[h], w[h], f32x2{a[k], a[k]});
 #pragma unroll
-        for (int h = 0; h < 2; ++h) p[h] = __builtin_elementwise_fma(p[h], t[h], f32x2{kc[k], kc[k]});
-#pragma unroll
-    for (int h = 0; h < 2; ++h) p[h] = __builtin_elementwise_fma(c[h], p[h], f32x2{0.5f, 0.5f});
+    for (int h = 0; h < 2; ++h) p[h] = pk_fma_clamp01(x[h], p[h], f32x2{0.5f, 0.5f});
 #pragma unroll
     for (int h = 0; h < 2; ++h) x[h] = x[h] * p[h];
     return f32x4{x[0][0], x[0][1], x[1][0], x[1][1]};
 }
+// degree by result type: what the rounding of the stored value hides (fp16 11 bits, bf16 8, e4m3 4)
+template <typename T> struct GeluDeg { static constexpr int value = 9; };
+template <> struct GeluDeg<BF16> { static constexpr int value = 8; };
+template <> struct GeluDeg<E4M3> { static constexpr int value = 6; };
 
 // sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15), result in every lane of the row
 template <int CTRL>
@@ -121,8 +142,8 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// value of one accumulator quad for the 16-bit epilogues
-template <int EPI>
+// value of one accumulator quad for the 16-bit epilogues; TR = the type the caller rounds the quad to (selects the GELU degree)
+template <int EPI, typename TR>
 __device__ __forceinline__ f32x4 epi_value16(f32x4 acc, f32x4 bv, f32x4 cv, float mean_rstd, float rstd) {
     f32x4 v;
     if constexpr (epi_is_lnfold(EPI)) {
@@ -132,7 +153,7 @@ __device__ __forceinline__ f32x4 epi_value16(f32x4 acc, f32x4 bv, f32x4 cv, floa
         v = acc + bv;
     }
     if constexpr (epi_has_gelu(EPI) && !(VH_EPI_ABL & 32)) {
-        v = gelu_poly4(v);
+        v = gelu_poly4<GeluDeg<TR>::value>(v);
     }
     return v;
 }
@@ -186,7 +207,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
             const int n = n0 + ni * 16;
             if (GUARD && n >= N) continue;
             if constexpr (epi_is_16bit(EPI)) {
-                const f32x4 v = epi_value16<EPI>(acc[mi][ni], bv[ni], cv[ni], mr, rstd);
+                const f32x4 v = epi_value16<EPI, T>(acc[mi][ni], bv[ni], cv[ni], mr, rstd);
                 *(typename T::vec4*)((elem*)e.out + orow * N + n) = pack4<T>(v[0], v[1], v[2], v[3]);
             } else {
                 const f32x4 v = acc[mi][ni] + bv[ni];
@@ -256,7 +277,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const f32x4 v = epi_value16<EPI>(acc[h * SMI + mi][ni], bv[ni], cv[ni], mr, rstd);
+                    const f32x4 v = epi_value16<EPI, T>(acc[h * SMI + mi][ni], bv[ni], cv[ni], mr, rstd);
                     const int c = ni * 2 + (fq >> 1);
                     *(typename T::vec4*)(sw + r * 128 + ((c ^ (r & 7)) << 4) + (fq & 1) * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
                 }
@@ -532,7 +553,7 @@ __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const
     uint8_t* const out = (uint8_t*)e.out;
     // LNFOLD_GELU (fp8 path with the folded LayerNorm): v = gelu(rstd_m * (acc - mean_m * c_n) + d_n), as epi_value16
     auto value = [&](const f32x4& a, const f32x4& b, const f32x4& cq = f32x4{0.f, 0.f, 0.f, 0.f}, float mean_rstd = 0.f, float rstd = 0.f) {
-        f32x4 v = epi_value16<EPI>(a, b, cq, mean_rstd, rstd);
+        f32x4 v = epi_value16<EPI, E4M3>(a, b, cq, mean_rstd, rstd);
         return pack4_e4m3(v[0], v[1], v[2], v[3]);
     };
     if (n_full || epi_is_lnfold(EPI)) {   // LN fold: staged form only, N % tile == 0 guaranteed

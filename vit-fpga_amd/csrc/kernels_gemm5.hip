@@ -58,8 +58,13 @@ namespace vh {
 
 #ifndef VH_MAIN_ABL
 #define VH_MAIN_ABL 0   // timing-only ablation builds (tools/build_abl.sh), 16-bit form: 1 no MFMAs, 2 no fragment reads, 4 fragment
-                        // reads in the workgroup's first K-tile only (real operands, then none), 8 no DMA after the prologue, 16 no barriers, 32 no s_setprio(1)
+                        // reads in the workgroup's first K-tile only (real operands, then none), 8 no DMA after the prologue, 16 no barriers, 32 no s_setprio(1),
+                        // 64 (round 4) the K-tile of a 256x128 workgroup tile with 64x64 wave tiles -- the geometry that has room for a
+                        // SECOND accumulator set -- emulated in this loop: half the MFMAs (16 per compute phase), half the activation
+                        // fragment reads, and 6 instead of 8 DMA pieces per wave and K-tile (the W operand is 128 rows: 2 pieces per wave)
 #endif
+constexpr int kAblHalf = (VH_MAIN_ABL & 64) ? 1 : 0;
+constexpr int kWPieces = kAblHalf ? 2 : 4;   // DMA pieces of the W operand per wave and K-tile (the counted waits follow)
 // ---- DIAGNOSTIC BUILD ONLY (-DVH_DIAG_STAMPS -> libvithip_diag.so, tools/gemm_anatomy.py) ---------------------------
 // Wave 0 of every workgroup stamps s_memrealtime (100 MHz, chip-wide) at: kernel entry, first K-tile visible, end of
 // the main loop, epilogue issued, stores drained; s_memtime (shader clock) around the main loop (in-kernel clock =
@@ -205,15 +210,16 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     auto a_off = [&](int kt, int kt3) { return AST == 2 ? ((par + kt) & 1) * STAGE_BYTES : 2 * W_OFF + kt3 * 32768; };
     auto w_off = [&](int kt) { return AST == 2 ? ((par + kt) & 1) * STAGE_BYTES + W_OFF : (kt & 1) * W_OFF; };
     bool dma_on = true;   // VH_MAIN_ABL & 8 only
-    auto dma4 = [&](const char* base, const uint32_t (&off)[4], char* dst) {
+    auto dma4 = [&](const char* base, const uint32_t (&off)[4], char* dst, int pieces = 4) {
         if constexpr (VH_MAIN_ABL & 8) { if (!dma_on) return; }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
+            if (i < pieces)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + off[i]),
                                              (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
     };
     auto issue_a = [&](int kt, int kt3 = 0) { dma4(cur.a + (int64_t)kt * KT_BYTES, cur.oa, smem + a_off(kt, kt3) + dma_off); };
-    auto issue_w = [&](int kt) { dma4(cur.w + (int64_t)kt * KT_BYTES, PERSIST ? cur.oa : cur.ow, smem + w_off(kt) + dma_off); };
+    auto issue_w = [&](int kt) { dma4(cur.w + (int64_t)kt * KT_BYTES, PERSIST ? cur.oa : cur.ow, smem + w_off(kt) + dma_off, kWPieces); };
 
     // ---- fragment addresses ----------------------------------------------------------------------------------
     const int frow = lane & 15, fq = lane >> 4;
@@ -233,7 +239,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         issue_w(1);
         issue_a(1, 1);
     }
-    if (nk > 1) pp_wait_vmcnt<8>();  // K-tile 0 landed, K-tile 1 may fly
+    if (nk > 1) pp_wait_vmcnt<4 + kWPieces>();  // K-tile 0 landed, K-tile 1 may fly
     else pp_wait_vmcnt<0>();
     pp_barrier();                    // K-tile 0 visible
     if constexpr (VH_MAIN_ABL & 8) dma_on = false;
@@ -278,15 +284,15 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         auto l1_issue_wait = [&](int kt) {
             if (kt + 2 < nk) {
                 issue_w(kt + 2);
-                pp_wait_vmcnt<8>();   // all but A(k+1) | W(k+2) (AST 3: A(k+2), W(k+2)) => W(k+1) landed
+                pp_wait_vmcnt<4 + kWPieces>();   // all but A(k+1) | W(k+2) (AST 3: A(k+2), W(k+2)) => W(k+1) landed
             } else if (has_next) {
                 if (kt + 2 == nk) {   // no W issue of this tile is left; the W base moves on to the next tile
                     cur.w = base_w(tn_n);
-                    dma4(cur.w, cur.oa, smem + w_off(nk) + dma_off);
+                    dma4(cur.w, cur.oa, smem + w_off(nk) + dma_off, kWPieces);
                 } else {
-                    dma4(cur.w + KT_BYTES, cur.oa, smem + w_off(nk + 1) + dma_off);
+                    dma4(cur.w + KT_BYTES, cur.oa, smem + w_off(nk + 1) + dma_off, kWPieces);
                 }
-                pp_wait_vmcnt<8>();
+                pp_wait_vmcnt<4 + kWPieces>();
             } else if (AST == 2 && kt + 1 < nk) {
                 pp_wait_vmcnt<4>();
             } else {
@@ -295,7 +301,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         };
         auto c1_wait = [&](int kt) {
             if (AST == 2) {
-                if (kt + 2 < nk || has_next) pp_wait_vmcnt<4>();   // all but W(k+2) => A(k+1) landed
+                if (kt + 2 < nk || has_next) pp_wait_vmcnt<kWPieces>();   // all but W(k+2) => A(k+1) landed
                 else pp_wait_vmcnt<0>();
             }
         };
@@ -346,6 +352,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             }
         } else {
         vec8 wf0[NI], wf1[NI], xf[MI];
+        constexpr int MI_A = kAblHalf ? MI / 2 : MI;   // row blocks of the wave tile that are read and multiplied (ablation 64: half)
         for (int kt = 0, k3 = 0; kt < nk; ++kt, k3 = k3 == 2 ? 0 : k3 + 1) {
             const char* sa = smem + a_off(kt, k3) + xbase;
             const char* sw = smem + w_off(kt) + wbase;
@@ -362,7 +369,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                 wf1[ni] = *(const vec8*)(sw + ni * 2048 + off1);
             }
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
+            for (int mi = 0; mi < MI_A; ++mi) {
                 if constexpr (VH_MAIN_ABL & 2) { asm volatile("" : "=v"(xf[mi])); continue; }
                 if constexpr (VH_MAIN_ABL & 4) { if (!(first && kt == 0)) { asm volatile("" : "+v"(xf[mi])); continue; } }
                 xf[mi] = *(const vec8*)(sa + mi * 2048 + off0);
@@ -375,7 +382,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // ---- C0 ------------------------------------------------------------------------------------------------
             if constexpr (!(VH_MAIN_ABL & 32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI_A; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     if constexpr (VH_MAIN_ABL & 1) asm volatile("" : "+v"(acc[mi][ni]) : "v"(wf0[ni]), "v"(xf[mi]));
@@ -387,7 +394,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             VH_PSTAMP(4);
             // ---- L1 ------------------------------------------------------------------------------------------------
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
+            for (int mi = 0; mi < MI_A; ++mi) {
                 if constexpr (VH_MAIN_ABL & 2) { asm volatile("" : "=v"(xf[mi])); continue; }
                 if constexpr (VH_MAIN_ABL & 4) { asm volatile("" : "+v"(xf[mi])); continue; }
                 xf[mi] = *(const vec8*)(sa + mi * 2048 + off1);
@@ -400,7 +407,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // ---- C1 ------------------------------------------------------------------------------------------------
             if constexpr (!(VH_MAIN_ABL & 32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI_A; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     if constexpr (VH_MAIN_ABL & 1) asm volatile("" : "+v"(acc[mi][ni]) : "v"(wf1[ni]), "v"(xf[mi]));
