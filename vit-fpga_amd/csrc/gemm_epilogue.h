@@ -229,9 +229,17 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
 // SMI = 16-row blocks staged per pass for 16-bit output (slice = SMI * 2 KiB per wave); fp32 stages SMI/2.
 // MFULL: every row of the wave's sub-tile is inside M (all but the last row tile of a GEMM): the 16-bit store loop then
 // carries no per-row predicate, so the read-backs of a pass are issued together instead of one per predicated block.
+// prio_grp (>= 0: the wave group 0 / 1 of the ping-pong kernel; -1: off), 16-bit forms with VH_EPI_PRIO: the two waves of a
+// SIMD run this epilogue at the same time and the vector ALU is arbitrated by priority, then AGE -- the older wave (group 0) got
+// nearly the full single-wave rate, finished early and waited ~3 us at the next tile's first barrier while group 1 finished ALONE
+// at the single-wave rate (4.7 cycles per packed instruction where two waves together manage one per 3.3: tools/probe_valu.hip,
+// profiles/r04_c_gemm_anatomy_tile8.txt).  Alternating the priority pass by pass lets both advance and finish together.
+#ifndef VH_EPI_PRIO
+#define VH_EPI_PRIO 1
+#endif
 template <typename T, int EPI, int MI, int NI, int SMI = MI, bool MFULL = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w,
-                                                     int lane, char* sw) {
+                                                     int lane, char* sw, int prio_grp = -1) {
     static_assert(NI == 4, "staged epilogue assumes a 64-column wave tile");
     static_assert(MI % SMI == 0 && SMI % 2 == 0, "slice must divide the wave tile");
     using elem = typename T::elem;
@@ -266,6 +274,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
         }
 #pragma unroll
         for (int h = 0; h < MI / SMI; ++h) {
+            if constexpr (VH_EPI_PRIO) {
+                if (prio_grp >= 0) {   // (wave-uniform)
+                    if ((h + prio_grp) & 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+            }
 #pragma unroll
             for (int mi = 0; mi < SMI; ++mi) {
                 const int r = mi * 16 + frow;
@@ -292,6 +306,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 else if (MFULL || m < M) epi_store(v, (u32x4*)((elem*)e.out + (int64_t)m * N + n));
             }
         }
+        if constexpr (VH_EPI_PRIO) { if (prio_grp >= 0) __builtin_amdgcn_s_setprio(0); }
     } else if constexpr (EPI == VH_EPI_RESID_SPLIT && std::is_same<T, E4M3>::value) {
         // split residual of the fp8 path: hi = e4m3(x), one byte, which IS the next GEMM's A operand; lo = bf16(x - hi), so the
         // pair carries 4 + 8 significant bits of x (the same 12 as the bf16 path's planes) in 3 bytes: a residual update

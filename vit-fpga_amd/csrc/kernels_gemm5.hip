@@ -464,7 +464,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             else if constexpr (F8 && (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT))
                 gemm_epilogue_staged<E4M3, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
             else
-                gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
+                gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE, epi_is_16bit(EPI) ? grp : -1);
         } else {
             if constexpr (F8 && epi_has_gelu(EPI))
                 gemm_epilogue8<EPI, MI, NI, VH_PP_SMI>(acc, e, m_w, n_w, lane_e, n_full, stage_epi, wave);
