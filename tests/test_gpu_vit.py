@@ -73,11 +73,15 @@ def test_vit_large_384_long_sequence_config():
     ctx.close()
 
 
-def test_vit_large_384_fp16_is_inside_the_north_star_tolerance_on_16_images():
-    """BASELINE config 4's parity claim on a sample that can show its margin: ViT-L/16 at 384x384, fp16, 16 images, default
-    flags (the guarded fold, the two-plane residual with the one-byte lo plane); the WORST image must be inside 1e-3.
-    24 layers leave less room than ViT-B's 12 (measured 9.2e-4 worst / 8.0e-4 median on these 16 images, profiles/r04_*): the
-    fp32-residual build of the same tree measures the same (9.3e-4), so what is left is the 16-bit operand format, not the planes."""
+def test_vit_large_384_fp16_on_16_images_median_inside_worst_at_the_edge_of_the_north_star_tolerance():
+    """BASELINE config 4 on a sample that shows its margin: ViT-L/16 at 384x384, fp16, 16 images, default flags (the guarded
+    fold, the two-plane residual with the one-byte lo plane).  What 24 layers of 16-bit operands leave, measured in round 4:
+    median 7.8-8.0e-4; the WORST of 16 images 9.2e-4 on one build and 1.02e-3 on the next (the GELU polynomial changed, to a
+    MORE accurate one: which image is worst, and by how much, is decided by rounding noise); 64 images: 1.03-1.07e-3 on either
+    LayerNorm path, and the fp32-residual build measures the same as the planes (profiles/r04_a_*, r04_b_*).  So the honest
+    claim for config 4 is NOT "every image inside 1e-3", and this test does not pretend it: it holds the median inside 9e-4,
+    at least 14 of the 16 images inside 1e-3, and the worst inside 1.15e-3 -- a regression bound on the tail, labelled as such
+    (DESIGN.md section 5).  ViT-B/16, the headline model, is asserted at 1e-3 on 64 images below."""
     cfg = S.CONFIGS["vit_large_384"]
     n = 16
     blob, images = S.make_blob(cfg, 0), S.make_images(cfg, 1, n)
@@ -88,8 +92,14 @@ def test_vit_large_384_fp16_is_inside_the_north_star_tolerance_on_16_images():
     got = ctx.forward(images)
     ctx.close()
     per = np.abs(got - ref).max(1) / np.abs(ref).max()
-    print(f"\n[parity] vit_large_384 fp16 {n} images, default flags: worst {per.max():.3e} median {np.median(per):.3e}")
-    assert np.isfinite(got).all() and per.max() <= NORTH_STAR, per.max()
+    inside = int((per <= NORTH_STAR).sum())
+    print(f"\n[parity] vit_large_384 fp16 {n} images, default flags: worst {per.max():.3e} median {np.median(per):.3e}; "
+          f"{inside} of {n} images inside 1e-3")
+    assert np.isfinite(got).all()
+    assert np.median(per) <= 9.0e-4, np.median(per)
+    assert inside >= 14, (inside, per.max())
+    assert per.max() <= 1.15e-3, per.max()             # tail regression bound: NOT the north star's tolerance
+    assert (got.argmax(1) == ref.argmax(1)).all()
 
 
 @pytest.mark.parametrize("flags,label", [(vithip.FLAG_LN_FOLD_ON, "folded"), (vithip.FLAG_LN_FOLD_OFF, "stand-alone")])
@@ -108,6 +118,25 @@ def test_fp16_is_inside_the_north_star_tolerance_on_64_vit_b_images(flags, label
     per = np.abs(got - ref).max(1) / np.abs(ref).max()
     print(f"\n[parity] vit_base fp16 {n} images, LayerNorm {label}: worst {per.max():.3e} median {np.median(per):.3e}")
     assert per.max() <= NORTH_STAR, per.max()
+
+
+@pytest.mark.parametrize("name,batch,dtype_name", [("vit_base", 3, "bf16"), ("vit_base", 70, "fp16"), ("vit_large_384", 1, "fp16")])
+def test_patch_embedding_with_the_gather_inside_the_gemm_gives_the_same_bits(monkeypatch, name, batch, dtype_name):
+    """VH_PATCH_FUSED=1: the patch GEMM reads the NHWC fp32 images itself (kernels_patch.hip: register-path A loader, no patch
+    matrix in memory) instead of im2col + GEMM.  Same conversion of every pixel, same k order in every MFMA, same epilogue:
+    the logits must be bit-identical -- also where the last row tile is ragged (batch 3 and 70: 588 / 13 720 GEMM rows)."""
+    cfg = S.CONFIGS[name]
+    dt = {"bf16": vithip.DTYPE_BF16, "fp16": vithip.DTYPE_FP16}[dtype_name]
+    images = S.make_images(cfg, 5, batch)
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("VH_PATCH_FUSED", fused)
+        ctx = vithip.VitContext(cfg, dtype=dt, max_batch=batch)
+        ctx.init_weights_seeded(0)
+        assert ctx.ln_fold()
+        outs.append(ctx.forward(images))
+        ctx.close()
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
 
 
 def test_layernorm_fold_is_a_property_of_the_configuration_not_of_the_workspace_size():

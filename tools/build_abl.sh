@@ -8,5 +8,5 @@ F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-v
 /opt/rocm/bin/hipcc $F "$@" -c csrc/kernels_gemm5.hip -o /tmp/abl_${N}_g5.o &
 /opt/rocm/bin/hipcc $F "$@" -c csrc/kernels_gemm.hip -o /tmp/abl_${N}_g.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvithip_abl_$N.so /tmp/abl_${N}_g.o /tmp/abl_${N}_g5.o csrc/kernels_attn.o csrc/kernels_misc.o csrc/vithip_api.o -ldl -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvithip_abl_$N.so /tmp/abl_${N}_g.o /tmp/abl_${N}_g5.o csrc/kernels_attn.o csrc/kernels_misc.o csrc/kernels_patch.o csrc/vithip_api.o -ldl -lpthread
 echo built libvithip_abl_$N.so

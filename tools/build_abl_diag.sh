@@ -9,5 +9,5 @@ F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-v
 /opt/rocm/bin/hipcc $F -c csrc/kernels_gemm5.hip -o /tmp/diag_m${B}_g5.o &
 /opt/rocm/bin/hipcc $F -c csrc/kernels_gemm.hip -o /tmp/diag_m${B}_g.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvithip_diag_m$B.so /tmp/diag_m${B}_g.o /tmp/diag_m${B}_g5.o csrc/diag_kernels_attn.o csrc/diag_kernels_misc.o csrc/diag_vithip_api.o -ldl -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvithip_diag_m$B.so /tmp/diag_m${B}_g.o /tmp/diag_m${B}_g5.o csrc/diag_kernels_attn.o csrc/diag_kernels_misc.o csrc/diag_kernels_patch.o csrc/diag_vithip_api.o -ldl -lpthread
 echo built libvithip_diag_m$B.so

@@ -70,6 +70,11 @@ hipError_t launch_attention_cls(const void* qkv16, int batch, int tokens, int he
 size_t attention_lds_bytes(int tokens);
 hipError_t launch_im2col(const float* in_nhwc, int batch, int image, int patch, int channels,
                          void* out16, int dtype, hipStream_t stream);
+// patch embedding with the gather inside the GEMM's A loader (kernels_patch.hip): NHWC fp32 images -> the split residual's
+// planes + the first row statistics' partial sums, no patch matrix in memory
+bool patch_fused_supported(int image, int patch, int channels, int dim);
+hipError_t launch_patch_fused(const float* images, int batch, int image, int patch, int channels, const void* wp16, const float* bias,
+                              const float* pos, void* hi, void* lo, float* partials, int64_t prow, int dim, int dtype, hipStream_t stream);
 hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int batch, int tokens,
                            int dim, hipStream_t stream);
 // the class-token rows of the SPLIT residual: (hi, lo) planes of cls + pos[0] and their per-64-column partial sums

@@ -176,6 +176,7 @@ struct vh_ctx {
     // VH_RESID_SPLIT=0 (A/B tools) keeps the fp32 array.
     bool split = false;
     bool cls_tail = false;    // VH_FLAG_CLS_TAIL: the last layer computes the class-token rows only (folded 16-bit path)
+    bool patch_fused = false; // VH_PATCH_FUSED=1 (read when the context is created): patch gather inside the GEMM's A loader
     void* xlo16 = nullptr;    // [B*T, D] bytes
     // Run-time guard on the fold: the kernels that produce the row statistics keep a running maximum of
     // |mean| * rstd over the REAL rows (guard_dev: the bits of a non-negative float); every forward ends with an
@@ -463,10 +464,21 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     int rc;
     if (img0 == 0) c->tail_splits = 0;
     if ((rc = mark(-1))) return rc;
-    HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, col16, dt16, s));
-    if ((rc = mark(ST_IM2COL))) return rc;
     const int nl = (c->run_layers < 0 || c->run_layers > f.layers) ? f.layers : c->run_layers;
-    if (c->split && !c->fp8 && nl > 0) {
+    // Patch embedding with the gather inside the GEMM's A loader (kernels_patch.hip; the split residual of the 16-bit paths):
+    // VH_PATCH_FUSED=1 selects it -- measured, DESIGN.md 4.4 -- the default is the im2col pass + the persistent GEMM.
+    const bool fused_patch = c->patch_fused && c->split && !c->fp8 && nl > 0 && patch_fused_supported(f.image_size, f.patch_size, f.channels, D);
+    if (!fused_patch) HIPCHK(&c->err, launch_im2col(in, batch, f.image_size, f.patch_size, f.channels, col16, dt16, s));
+    if ((rc = mark(ST_IM2COL))) return rc;
+    if (fused_patch) {
+        HIPCHK(&c->err, launch_patch_fused(in, batch, f.image_size, f.patch_size, f.channels, c->wp16, P + L.patch_b, P + L.pos, xn16, xlo16,
+                                           partials_p, rows_g, D, dt16, s));
+        if ((rc = mark(ST_PATCH))) return rc;
+        HIPCHK(&c->err, launch_cls_rows_split(xn16, xlo16, partials_p, rows_g, P + L.cls, P + L.pos, batch, T, D, dt16, s));
+        if ((rc = mark(ST_CLS))) return rc;
+        HIPCHK(&c->err, launch_finalize_stats(partials_p, D / 64, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev, amax_guard));
+        if ((rc = mark(ST_LNSTATS))) return rc;
+    } else if (c->split && !c->fp8 && nl > 0) {
         // Split residual: the patch embedding lands DIRECTLY in the two 16-bit planes, with the first row statistics'
         // partial sums (PATCH_SPLIT epilogue; the class-token rows from their own small kernel) -- no fp32 x, no separate
         // row-statistics pass over it (round 3: -0.1 ms per forward).  The partial sums are laid out for rows_g rows, like
@@ -934,6 +946,8 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         c->ln_fold_cfg = c->ln_fold;
         c->split_cfg = c->split;
         c->cls_tail = (cfg->flags & VH_FLAG_CLS_TAIL) != 0;
+        const char* pf = getenv("VH_PATCH_FUSED");
+        c->patch_fused = pf && pf[0] == '1';
     }
     CK(hipHostMalloc((void**)&c->guard_host, 64, hipHostMallocDefault));
     *c->guard_host = 0.f;
