@@ -274,7 +274,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
         }
 #pragma unroll
         for (int h = 0; h < MI / SMI; ++h) {
-            if constexpr (VH_EPI_PRIO) {
+            if constexpr (VH_EPI_PRIO == 1) {
                 if (prio_grp >= 0) {   // (wave-uniform)
                     if ((h + prio_grp) & 1) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
@@ -282,6 +282,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
             }
 #pragma unroll
             for (int mi = 0; mi < SMI; ++mi) {
+                if constexpr (VH_EPI_PRIO == 2) {   // (A/B: flip per 16-row block instead of per pass)
+                    if (prio_grp >= 0) {
+                        if ((h * SMI + mi + prio_grp) & 1) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+                }
                 const int r = mi * 16 + frow;
                 float rstd = 0.f, mr = 0.f;
                 if constexpr (epi_is_lnfold(EPI)) {
