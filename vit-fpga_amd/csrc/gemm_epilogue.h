@@ -237,6 +237,9 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
 #ifndef VH_EPI_PRIO
 #define VH_EPI_PRIO 1
 #endif
+#ifndef VH_EPI_TILED_EXP
+#define VH_EPI_TILED_EXP 0
+#endif
 template <typename T, int EPI, int MI, int NI, int SMI = MI, bool MFULL = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w,
                                                      int lane, char* sw, int prio_grp = -1) {
@@ -258,6 +261,37 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) asm volatile("" :: "v"(acc[mi][ni]));
+    } else if constexpr (epi_is_16bit(EPI) && epi_has_gelu(EPI) && MFULL && VH_EPI_TILED_EXP) {
+        // EXPERIMENT (timing only unless the consumer reads the same layout): the result in a 16-row-blocked layout
+        // [m / 16][N / 8 chunks][16 rows][8 values], columns of a 64-block in the order a lane holds them (pairs of quads), so that a
+        // lane's two quads of a row are 16 contiguous bytes and the sixteen rows of a 16-lane group are 256 contiguous bytes: direct
+        // 16-byte stores from the registers, no LDS transposition.
+        float2 lnst[epi_is_lnfold(EPI) ? MI : 1];
+        if constexpr (epi_is_lnfold(EPI)) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)(m_w + mi * 16 + frow));
+        }
+        char* const obase = (char*)e.out + ((int64_t)(m_w >> 4) * (N >> 3) + (n_w >> 3)) * 256 + frow * 16 + fq * 256;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if constexpr (VH_EPI_PRIO == 1) {
+                if (prio_grp >= 0 && (mi & 1) == 0) {
+                    if (((mi >> 1) + prio_grp) & 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+            }
+            float rstd = 0.f, mr = 0.f;
+            if constexpr (epi_is_lnfold(EPI)) { rstd = lnst[mi].y; mr = lnst[mi].x * lnst[mi].y; }
+#pragma unroll
+            for (int j = 0; j < NI / 2; ++j) {
+                const f32x4 v0 = epi_value16<EPI, T>(acc[mi][2 * j], bv[2 * j], cv[2 * j], mr, rstd);
+                const f32x4 v1 = epi_value16<EPI, T>(acc[mi][2 * j + 1], bv[2 * j + 1], cv[2 * j + 1], mr, rstd);
+                const typename T::vec4 p0 = pack4<T>(v0[0], v0[1], v0[2], v0[3]), p1 = pack4<T>(v1[0], v1[1], v1[2], v1[3]);
+                const u32x2 a = __builtin_bit_cast(u32x2, p0), b = __builtin_bit_cast(u32x2, p1);
+                epi_store(u32x4{a[0], a[1], b[0], b[1]}, (u32x4*)(obase + (int64_t)mi * (N >> 3) * 256 + j * 1024));
+            }
+        }
+        if constexpr (VH_EPI_PRIO == 1) { if (prio_grp >= 0) __builtin_amdgcn_s_setprio(0); }
     } else if constexpr (epi_is_16bit(EPI)) {
         // rows of 64 x 16-bit = 128 B = 8 chunks of 16 B; chunk c of row r lives at chunk c ^ (r & 7)
         const int rr = lane >> 3, pc = lane & 7;
