@@ -257,7 +257,11 @@ int vh_get_step_timing(vh_ctx* ctx, double* step_ms, int max_steps, int* steps);
 /* debug taps: copy an internal activation of the LAST forward to the host as fp32.
  * what: 0 = residual stream x [batch*T, D] after the last layer run,
  *       1 = final-LN'd CLS rows [batch, D],
- *       2 = one float: how many residual GEMMs of the last forward ran as a split launch (VH_TAIL_OVERLAP=1). */
+ *       2 = one float: how many residual GEMMs of the last forward ran as a split launch (VH_TAIL_OVERLAP=1),
+ *       3 = one float: 1 when the last forward kept the MLP hidden activation in its tiled (16-row-blocked) layout -- the
+ *           default wherever both MLP GEMMs take the persistent form (16-bit folded path, whole 256-row tiles; VH_H_TILED=0 at
+ *           context creation keeps it row-major): same values, same logit bits, fc1's result leaves the registers without an
+ *           LDS transposition. */
 int vh_debug_read(vh_ctx* ctx, int what, float* host_out, size_t n_floats);
 /* run only the first `n_layers` encoder layers on the next forwards (-1 = all) */
 int vh_debug_set_layers(vh_ctx* ctx, int n_layers);

@@ -139,6 +139,32 @@ def test_patch_embedding_with_the_gather_inside_the_gemm_gives_the_same_bits(mon
     assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("name,batch,dtype_name", [("vit_base", 256, "bf16"), ("vit_base", 300, "fp16"), ("vit_large_384", 64, "fp16")])
+def test_tiled_hidden_activation_gives_the_same_bits_as_the_row_major_one(monkeypatch, name, batch, dtype_name):
+    """Round 4: where both MLP GEMMs take the persistent form, fc1 writes the hidden activation h in a 16-row-blocked layout
+    straight from its registers (no LDS transposition) and fc2's operand DMA reads h and a tiled copy of its weights in that
+    layout.  Natural column order inside every chunk, so every MFMA sees the same k order: the logits must equal the row-major
+    path's bit for bit (VH_H_TILED=0) -- on exact tiles (batch 256), on rows padded to whole tiles (300) and on ViT-L."""
+    cfg = S.CONFIGS[name]
+    dt = {"bf16": vithip.DTYPE_BF16, "fp16": vithip.DTYPE_FP16}[dtype_name]
+    px = cfg["image_size"] ** 2 * cfg["channels"]
+    din, dout = vithip.DeviceBuffer(batch * px * 4), vithip.DeviceBuffer(batch * cfg["classes"] * 4)
+    outs, used = [], []
+    for tiled in ("0", "1"):
+        monkeypatch.setenv("VH_H_TILED", tiled)
+        ctx = vithip.VitContext(cfg, dtype=dt, max_batch=batch)
+        ctx.init_weights_seeded(0)
+        ctx.fill_input_seeded(1, batch, din.ptr)
+        ctx.forward_device(din.ptr, batch, dout.ptr)
+        outs.append(dout.to_numpy(np.float32, (batch, cfg["classes"])))
+        used.append(int(ctx.debug_read(3, 1)[0]))
+        small = ctx.forward(din.to_numpy(np.float32, (batch, cfg["image_size"], cfg["image_size"], cfg["channels"]))[:2])   # a batch too small for the persistent form
+        assert int(ctx.debug_read(3, 1)[0]) == 0 and np.array_equal(small, outs[-1][:2])
+        ctx.close()
+    assert used == [0, 1], used
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+
+
 def test_layernorm_fold_is_a_property_of_the_configuration_not_of_the_workspace_size():
     """The same image gives the same logit BITS from a context sized for 1 image and from one sized for 300 (the fold used
     to switch on with max_batch, so the numerics depended on how the workspace had been sized)."""

@@ -237,10 +237,9 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
 #ifndef VH_EPI_PRIO
 #define VH_EPI_PRIO 1
 #endif
-#ifndef VH_EPI_TILED_EXP
-#define VH_EPI_TILED_EXP 0
-#endif
-template <typename T, int EPI, int MI, int NI, int SMI = MI, bool MFULL = false>
+// OTILED (16-bit GELU forms, full tiles): the result goes to the 16-ROW-BLOCKED layout of the MLP hidden activation (below) straight
+// from the registers, without the LDS transposition.
+template <typename T, int EPI, int MI, int NI, int SMI = MI, bool MFULL = false, bool OTILED = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w,
                                                      int lane, char* sw, int prio_grp = -1) {
     static_assert(NI == 4, "staged epilogue assumes a 64-column wave tile");
@@ -261,21 +260,26 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) asm volatile("" :: "v"(acc[mi][ni]));
-    } else if constexpr (epi_is_16bit(EPI) && epi_has_gelu(EPI) && MFULL && VH_EPI_TILED_EXP) {
-        // EXPERIMENT (timing only unless the consumer reads the same layout): the result in a 16-row-blocked layout
-        // [m / 16][N / 8 chunks][16 rows][8 values], columns of a 64-block in the order a lane holds them (pairs of quads), so that a
-        // lane's two quads of a row are 16 contiguous bytes and the sixteen rows of a 16-lane group are 256 contiguous bytes: direct
-        // 16-byte stores from the registers, no LDS transposition.
+    } else if constexpr (epi_is_16bit(EPI) && epi_has_gelu(EPI) && MFULL && OTILED) {
+        // The MLP hidden activation h in its TILED layout (round 4): [m / 16][N / 8 chunks][16 rows][8 values] -- the sixteen rows of a
+        // 16-lane group are 256 contiguous bytes per chunk, so the result leaves the registers in 16-byte stores of whole 256-byte
+        // segments with NO LDS transposition (the staged form below costs 32 ds_write_b64 + 16 ds_read_b128 per wave and tile; a
+        // register path into a ROW-major result was measured slower in round 3 because a 16-lane group then touches sixteen rows).
+        // A lane holds 4 consecutive columns of column blocks ni = 2j and 2j + 1; one v_permlane16_swap per packed dword (odd 16-lane
+        // rows of the first operand <-> even rows of the second) leaves the lanes of an even row with the 8 consecutive columns
+        // 16 (2j) + 8 h .. + 7 and those of the odd row beside it with 16 (2j + 1) + 8 h .. + 7 (h = fq >> 1): NATURAL column order
+        // inside every chunk, so fc2 multiplies in the same k order as with a row-major h and the logits keep their bits.
+        // h has exactly one consumer, fc2's operand DMA (kernels_gemm5.hip AT), which takes per-lane source addresses anyway.
         float2 lnst[epi_is_lnfold(EPI) ? MI : 1];
         if constexpr (epi_is_lnfold(EPI)) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)(m_w + mi * 16 + frow));
         }
-        char* const obase = (char*)e.out + ((int64_t)(m_w >> 4) * (N >> 3) + (n_w >> 3)) * 256 + frow * 16 + fq * 256;
+        char* const obase = (char*)e.out + ((int64_t)(m_w >> 4) * (N >> 3) + (n_w >> 3) + (fq & 1) * 2 + (fq >> 1)) * 256 + frow * 16;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             if constexpr (VH_EPI_PRIO == 1) {
-                if (prio_grp >= 0 && (mi & 1) == 0) {
+                if (prio_grp >= 0 && (mi & 1) == 0) {   // (wave-uniform) the two wave groups alternate, as in the staged form
                     if (((mi >> 1) + prio_grp) & 1) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
                 }
@@ -286,9 +290,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
             for (int j = 0; j < NI / 2; ++j) {
                 const f32x4 v0 = epi_value16<EPI, T>(acc[mi][2 * j], bv[2 * j], cv[2 * j], mr, rstd);
                 const f32x4 v1 = epi_value16<EPI, T>(acc[mi][2 * j + 1], bv[2 * j + 1], cv[2 * j + 1], mr, rstd);
-                const typename T::vec4 p0 = pack4<T>(v0[0], v0[1], v0[2], v0[3]), p1 = pack4<T>(v1[0], v1[1], v1[2], v1[3]);
-                const u32x2 a = __builtin_bit_cast(u32x2, p0), b = __builtin_bit_cast(u32x2, p1);
-                epi_store(u32x4{a[0], a[1], b[0], b[1]}, (u32x4*)(obase + (int64_t)mi * (N >> 3) * 256 + j * 1024));
+                const u32x2 p0 = __builtin_bit_cast(u32x2, pack4<T>(v0[0], v0[1], v0[2], v0[3]));
+                const u32x2 p1 = __builtin_bit_cast(u32x2, pack4<T>(v1[0], v1[1], v1[2], v1[3]));
+                const auto sx = __builtin_amdgcn_permlane16_swap(p0[0], p1[0], false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(p0[1], p1[1], false, false);
+                epi_store(u32x4{sx[0], sy[0], sx[1], sy[1]}, (u32x4*)(obase + (int64_t)mi * (N >> 3) * 256 + j * 1024));
             }
         }
         if constexpr (VH_EPI_PRIO == 1) { if (prio_grp >= 0) __builtin_amdgcn_s_setprio(0); }

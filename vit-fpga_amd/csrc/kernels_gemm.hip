@@ -194,6 +194,11 @@ int gemm_pick_variant(int64_t M, int N, int epilogue) {
     return t256 >= min_tiles ? gemm_pp_variant(epilogue) : 1;  // the 256x256 ping-pong kernel needs enough tiles for the 256 CUs
 }
 
+// the persistent ping-pong form runs (launch_pp): enough tiles for the ping-pong kernel, whole 256 x 256 tiles, at least two K-tiles
+bool gemm_tiled_applies(int64_t M, int N, int K) {
+    return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K / 64 >= 2 && gemm_pick_variant(M, N, VH_EPI_BIAS) == 6;
+}
+
 const char* gemm_check(const GemmArgs& g) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return "gemm: empty shape";
     if (g.K % 64) return "gemm: K must be a multiple of 64";
@@ -216,6 +221,7 @@ const char* gemm_check(const GemmArgs& g) {
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
     if (gemm_check(g)) return hipErrorInvalidValue;
     const int variant = g.variant ? g.variant : gemm_pick_variant(g.M, g.N, g.epilogue);
+    if ((g.out_tiled || g.ab_tiled) && variant != 6) return hipErrorInvalidValue;   // tiled layouts exist in the persistent form only
     if ((g.tile_count || g.tile_begin) && variant != 5 && variant != 7) return hipErrorInvalidValue;  // tile ranges: ping-pong forms only
     return g.dtype == VH_DTYPE_BF16 ? launch_epi<BF16>(g, variant, s) : launch_epi<FP16>(g, variant, s);
 }

@@ -123,7 +123,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {  // bijective on [0, 
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
 }
 
-template <typename T, int EPI, bool PERSIST, bool F8 = false, int AST = 2>
+// OT: the 16-bit GELU result goes to the tiled layout of the MLP hidden activation (gemm_epilogue.h); AT: A and W are read from it
+// (16-row blocks: the per-lane DMA offsets and the K-tile stride change, nothing inside the K loop does).  Persistent form only.
+template <typename T, int EPI, bool PERSIST, bool F8 = false, int AST = 2, bool OT = false, bool AT = false>
 __global__ void __launch_bounds__(512, 2)
 gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                   const float* __restrict__ bias, void* __restrict__ outp, int M, int N, int K,
@@ -141,6 +143,8 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #endif
     constexpr int BM = 256, BN = 256;
     constexpr int KT_BYTES = 128;                  // one K-tile row: 64 16-bit or 128 8-bit elements
+    static_assert(!(OT || AT) || (PERSIST && !F8), "tiled layouts: persistent 16-bit form only");
+    constexpr int KT_STEP = AT ? 2048 : KT_BYTES;  // source bytes from one K-tile to the next (tiled: 8 chunks x 256 B)
     constexpr int STAGE_BYTES = 65536, W_OFF = 32768;
     // AST = number of LDS stages of the A (activation) operand.  2: stage s = [A 32 KiB | W 32 KiB] at s * 64 KiB.
     // 3 (variant 7): W stages at 0 / 32 KiB, A stages at 64 + 32 s KiB (160 KiB, the whole LDS): A of tile k+2 is
@@ -198,6 +202,12 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = grp * 128 + (i * 4 + wn) * 8 + lr;
+            // AT: the source is [16-row block][K / 8 chunks][16 rows][16 B], and the LDS image of a K-tile keeps that order (8 chunks x
+            // 256 B per row block): piece p = i * 4 + wn of the group's half is row block p >> 1, chunks 4 (p & 1) .. + 3 -- ONE KiB OF
+            // CONTIGUOUS SOURCE per DMA instruction, lane-linear on both sides (a first form that kept the row-major LDS image read
+            // 16-byte pieces 256 B apart from adjacent lanes: fc2 +35 %, the coalescer works on adjacent lanes)
+            if constexpr (AT) cur.oa[i] = (uint32_t)((grp * 8 + ((i * 4 + wn) >> 1)) * (rb * 16) + ((i * 4 + wn) & 1) * 1024 + lane * 16);
+            else
             cur.oa[i] = (uint32_t)((r < ma ? r : ma) * rb + lc * 16);
             if constexpr (!PERSIST) cur.ow[i] = (uint32_t)((r < mw ? r : mw) * rb + lc * 16);
         }
@@ -218,14 +228,15 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(base + off[i]),
                                              (void __attribute__((address_space(3)))*)(dst + i * 4096), 16, 0, 0);
     };
-    auto issue_a = [&](int kt, int kt3 = 0) { dma4(cur.a + (int64_t)kt * KT_BYTES, cur.oa, smem + a_off(kt, kt3) + dma_off); };
-    auto issue_w = [&](int kt) { dma4(cur.w + (int64_t)kt * KT_BYTES, PERSIST ? cur.oa : cur.ow, smem + w_off(kt) + dma_off, kWPieces); };
+    auto issue_a = [&](int kt, int kt3 = 0) { dma4(cur.a + (int64_t)kt * KT_STEP, cur.oa, smem + a_off(kt, kt3) + dma_off); };
+    auto issue_w = [&](int kt) { dma4(cur.w + (int64_t)kt * KT_STEP, PERSIST ? cur.oa : cur.ow, smem + w_off(kt) + dma_off, kWPieces); };
 
     // ---- fragment addresses ----------------------------------------------------------------------------------
     const int frow = lane & 15, fq = lane >> 4;
     // 16-bit: k-step 0 / 1 = chunk fq / 4+fq; fp8: the lane's 32 k-bytes = chunks 2fq and 2fq+1
-    const int off0 = frow * 128 + (((F8 ? 2 * fq : fq) ^ (frow & 7)) << 4);
-    const int off1 = frow * 128 + (((F8 ? 2 * fq + 1 : 4 | fq) ^ (frow & 7)) << 4);
+    // (AT: row block = 8 chunks x [16 rows x 16 B]; a fragment read takes 4 chunks x 16 rows = 1 KiB of contiguous LDS: no swizzle needed)
+    const int off0 = AT ? fq * 256 + frow * 16 : frow * 128 + (((F8 ? 2 * fq : fq) ^ (frow & 7)) << 4);
+    const int off1 = AT ? (4 + fq) * 256 + frow * 16 : frow * 128 + (((F8 ? 2 * fq + 1 : 4 | fq) ^ (frow & 7)) << 4);
     const int xbase = grp * 16384;          // rows 128*grp ..  (inside an A stage)
     const int wbase = wn * 8192;            // rows 64*wn ..    (inside a W stage)
 
@@ -290,7 +301,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                     cur.w = base_w(tn_n);
                     dma4(cur.w, cur.oa, smem + w_off(nk) + dma_off, kWPieces);
                 } else {
-                    dma4(cur.w + KT_BYTES, cur.oa, smem + w_off(nk + 1) + dma_off, kWPieces);
+                    dma4(cur.w + KT_STEP, cur.oa, smem + w_off(nk + 1) + dma_off, kWPieces);
                 }
                 pp_wait_vmcnt<4 + kWPieces>();
             } else if (AST == 2 && kt + 1 < nk) {
@@ -464,7 +475,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             else if constexpr (F8 && (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT))
                 gemm_epilogue_staged<E4M3, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
             else
-                gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE, epi_is_16bit(EPI) ? grp : -1);
+                gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true, OT>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE, epi_is_16bit(EPI) ? grp : -1);
         } else {
             if constexpr (F8 && epi_has_gelu(EPI))
                 gemm_epilogue8<EPI, MI, NI, VH_PP_SMI>(acc, e, m_w, n_w, lane_e, n_full, stage_epi, wave);
@@ -527,10 +538,10 @@ static unsigned long long* diag_next(const GemmArgs& g, int epi, bool f8, int gr
 #endif
 
 // mode 0: one tile per workgroup (variant 5); 1: persistent (6); 2: one tile per workgroup, three A stages (7)
-template <typename T, int EPI, bool F8, bool PERSIST, int AST>
+template <typename T, int EPI, bool F8, bool PERSIST, int AST, bool OT = false, bool AT = false>
 static hipError_t launch_pp_one(const GemmArgs& g, int grid, int tiles_m, int tiles_n, hipStream_t s) {
     constexpr size_t lds = (AST == 3 || PERSIST) ? 163840 : 131072;
-    auto k = gemm_nt_pp_kernel<T, EPI, PERSIST, F8, AST>;
+    auto k = gemm_nt_pp_kernel<T, EPI, PERSIST, F8, AST, OT, AT>;
     static LdsDone lds_done;  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)k, lds, lds_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, g.a, g.w, g.bias, g.out, (int)g.M, g.N, g.K, g.aux, g.aux_i, tiles_m,
@@ -562,10 +573,18 @@ static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
         // CUs while the rest idle (batch 128: fc2 2.74 ms per forward against 1.96 ms in the one-tile form).  The
         // persistent form gains ~3 %, so it is worth that only when forced (variant 6 asked for explicitly).
         if (mode == 1 && full_m != tiles_m && g.variant != 6) mode = 0;
+        if ((g.out_tiled || g.ab_tiled) && (mode != 1 || full_m != tiles_m || F8)) return hipErrorInvalidValue;   // tiled layouts: persistent 16-bit form on whole tiles only
         if (mode == 1) {
             const int num_cu = device_num_cu();   // of the device this launch goes to (a group has one thread per device)
             if (!num_cu) return hipErrorUnknown;
             const int nfull = full_m * tiles_n;
+            if constexpr (!F8 && (EPI == VH_EPI_LNFOLD_GELU || EPI == VH_EPI_BIAS_GELU)) {
+                if (g.out_tiled) return g.ab_tiled ? hipErrorInvalidValue : launch_pp_one<T, EPI, F8, true, 2, true, false>(g, nfull < num_cu ? nfull : num_cu, full_m, tiles_n, s);
+            }
+            if constexpr (!F8 && (EPI == VH_EPI_RESID_SPLIT || EPI == VH_EPI_BIAS)) {
+                if (g.ab_tiled) return g.out_tiled ? hipErrorInvalidValue : launch_pp_one<T, EPI, F8, true, 2, false, true>(g, nfull < num_cu ? nfull : num_cu, full_m, tiles_n, s);
+            }
+            if (g.out_tiled || g.ab_tiled) return hipErrorInvalidValue;
             if (hipError_t e = launch_pp_one<T, EPI, F8, true, 2>(g, nfull < num_cu ? nfull : num_cu, full_m, tiles_n, s); e != hipSuccess) return e;
             if (full_m == tiles_m) return hipSuccess;
             GemmArgs tail = g;   // tiles [full_m * tiles_n, ntiles) of the n-fastest order = the ragged last row of tiles
@@ -574,6 +593,7 @@ static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
             return launch_pp_one<T, EPI, F8, false, 2>(tail, tiles_n, tiles_m, tiles_n, s);
         }
     }
+    if (g.out_tiled || g.ab_tiled) return hipErrorInvalidValue;
     return launch_pp_one<T, EPI, F8, false, 2>(g, ntiles, tiles_m, tiles_n, s);
 }
 

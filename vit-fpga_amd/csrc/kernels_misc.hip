@@ -183,6 +183,31 @@ hipError_t launch_cast(const float* in, void* out16, int64_t n, int dtype, hipSt
     return hipGetLastError();
 }
 
+// W fp32 [rows, cols] -> 16-bit in the TILED layout the MLP hidden activation has (gemm_epilogue.h OTILED, kernels_gemm5.hip AT):
+// [row / 16][cols / 8 chunks][16 rows][8 values], natural column order.  One thread per destination chunk.
+template <typename T>
+__global__ void __launch_bounds__(256) cast_tiled_w_kernel(const float* __restrict__ w, typename T::elem* __restrict__ out, int rows, int cols) {
+    const int64_t nchunk = (int64_t)rows * (cols >> 3);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r16 = (int)(i & 15);
+        const int64_t bc = i >> 4;                        // block * (cols / 8) + chunk
+        const int chunk = (int)(bc % (cols >> 3)), block = (int)(bc / (cols >> 3));
+        const float* src = w + (int64_t)(block * 16 + r16) * cols + chunk * 8;
+        const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+        const typename T::vec4 lo = pack4<T>(a[0], a[1], a[2], a[3]), hi = pack4<T>(b[0], b[1], b[2], b[3]);
+        *(typename T::vec8*)(out + i * 8) = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+hipError_t launch_cast_tiled_w(const float* w, int rows, int cols, void* w16, int dtype, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || (rows & 15) || (cols & 7)) return hipErrorInvalidValue;
+    const int64_t nchunk = (int64_t)rows * (cols >> 3);
+    const unsigned grid = (unsigned)((nchunk + 255) / 256 < 8192 ? (nchunk + 255) / 256 : 8192);
+    if (dtype == VH_DTYPE_BF16) hipLaunchKernelGGL(cast_tiled_w_kernel<BF16>, dim3(grid), dim3(256), 0, s, w, (BF16::elem*)w16, rows, cols);
+    else if (dtype == VH_DTYPE_FP16) hipLaunchKernelGGL(cast_tiled_w_kernel<FP16>, dim3(grid), dim3(256), 0, s, w, (FP16::elem*)w16, rows, cols);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // ---- synthetic data ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ out, int64_t n, uint64_t stream, int kind,
                                                    double scale, float offset) {

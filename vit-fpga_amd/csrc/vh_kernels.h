@@ -31,7 +31,15 @@ struct GemmArgs {
     int tile_begin = 0, tile_count = 0;
     // PATCH_SPLIT: row stride of `partials` = number of TOKEN rows the statistics buffer is laid out for (0 = images x tokens)
     int64_t prow = 0;
+    // The MLP hidden activation in its TILED layout (gemm_epilogue.h, OTILED; persistent 16-bit form only: the launcher
+    // refuses otherwise -- ask gemm_tiled_applies first).  out_tiled: an LNFOLD_GELU / BIAS_GELU launch writes it; ab_tiled: A and W
+    // of this launch are both in that layout (16-row blocks).
+    int out_tiled = 0, ab_tiled = 0;
 };
+// does a 16-bit GEMM of this shape take the persistent form, the only one that reads / writes the tiled layout?
+bool gemm_tiled_applies(int64_t M, int N, int K);
+// W fp32 [rows, cols] -> 16-bit in the tiled layout (16-row blocks, natural column order)
+hipError_t launch_cast_tiled_w(const float* w, int rows, int cols, void* w16, int dtype, hipStream_t stream);
 
 // row stride of the partial-sum buffer a launch writes: PATCH_SPLIT lands on token rows (images x (patches + 1) unless the
 // caller's buffer is laid out for more, e.g. rows padded to whole tiles); the other forms use their own M inside the kernel

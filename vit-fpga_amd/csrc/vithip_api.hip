@@ -159,6 +159,12 @@ struct vh_ctx {
     char* w16 = nullptr;      // arena of 16-bit matrices
     void* wp16 = nullptr;     // [D, KP]
     std::vector<void*> wqkv16, wo16, w1_16, w2_16;
+    // fc2's weights once more in the 16-row-blocked layout of the tiled hidden activation (h_tiled; 16-bit folded path): the MLP
+    // hidden activation then leaves fc1's epilogue straight from the registers (gemm_epilogue.h OTILED) and fc2's operand DMA reads
+    // both operands in that layout -- same values, same k order, same bits as the row-major path
+    std::vector<void*> w2t_16;
+    bool h_tiled = false;     // VH_H_TILED=0 (read when the context is created) keeps the row-major h (A/B, tests)
+    bool weights_ready_tiled = false;   // the tiled copies exist for the CURRENT weights (prepared with the fold on)
     float* bqkv = nullptr;    // [layers, 3D]
     // VH_DTYPE_FP8: the four per-layer matrices hold e4m3 bytes (in the same arena) + one fp32 scale per output channel;
     // everything 16-bit (patch embedding, qkv, head) is bf16
@@ -218,6 +224,7 @@ struct vh_ctx {
     hipStream_t tstream = nullptr;
     hipEvent_t ev_tail_a = nullptr, ev_tail_l = nullptr;
     bool tail_overlap = false;
+    bool last_h_tiled = false;   // debug tap 3
     int tail_splits = 0;   // residual GEMMs of the last forward that were launched as [full rounds] + [tail round] (debug tap 2)
     int num_cu = 256;
     // optional hipGraph replay of the forward's launch sequence (vh_set_graph): one instantiated graph per
@@ -354,10 +361,12 @@ int prepare_weights(vh_ctx* c) {
         }
         HIPCHK(&c->err, launch_cast(P + o.ow, c->wo16[l], (int64_t)D * D, f.dtype, s));
         HIPCHK(&c->err, launch_cast(P + o.f2w, c->w2_16[l], (int64_t)D * M, f.dtype, s));
+        if (c->h_tiled && c->w2t_16[l]) HIPCHK(&c->err, launch_cast_tiled_w(P + o.f2w, D, M, c->w2t_16[l], f.dtype, s));
         if (w8tmp) { HIPCHK(&c->err, hipStreamSynchronize(s)); }   // the scratch is reused by the next layer
     }
     HIPCHK(&c->err, hipStreamSynchronize(s));
     c->weights_ready = true;
+    c->weights_ready_tiled = c->h_tiled && !c->fp8;
     return VH_OK;
 }
 
@@ -508,6 +517,9 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     // the class-token tail needs the split planes of the folded 16-bit path, the whole model, and room in the patch-matrix buffer
     const bool tail = c->cls_tail && c->ln_fold && c->split && !c->fp8 && nl == f.layers && c->run_layers < 0 && T <= 1024 &&
                       (size_t)L.NP * L.KP * esz >= 2 * ((size_t)D * esz + 256);
+    // tiled hidden activation: both MLP GEMMs must take the persistent form (whole 256-row tiles, enough of them), the 16-bit split path
+    const bool h_tiled = c->h_tiled && c->split && !c->fp8 && c->weights_ready_tiled && gemm_tiled_applies(rows_g, M, D) && gemm_tiled_applies(rows_g, D, M);
+    c->last_h_tiled = h_tiled && nl > 0 && c->ln_fold;
     for (int l = 0; l < nl && c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
         const float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
@@ -562,10 +574,20 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         HIPCHK(&c->err, launch_finalize_stats(partials_p, nblk, rows_g, D, f.ln_eps, stats_p, s, rows, c->guard_dev, amax_guard));
         if ((rc = mark(ST_LNSTATS))) return rc;
         if ((rc = tmark(ST_FC1))) return rc;
+        if (h_tiled) {   // h in its tiled layout: written straight from fc1's registers, read by fc2's DMA (same values, same bits)
+            GemmArgs g1{xn16, c->w1_16[l], cd + 6 * D + M, h16, rows_g, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0, dt16, 0};
+            g1.stats = stats_p; g1.out_tiled = 1;
+            HIPCHK(&c->err, launch_gemm(g1, s));
+        } else
         HIPCHK(&c->err, gemm(xn16, c->w1_16[l], cd + 6 * D + M, h16, rows_g, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0, s1));
         if ((rc = tmark(ST_FC1))) return rc;
         if ((rc = mark(ST_FC1))) return rc;
         if ((rc = tmark(ST_FC2))) return rc;
+        if (h_tiled) {
+            GemmArgs g2{h16, c->w2t_16[l], P + o.f2b, xn16, rows_g, D, M, VH_EPI_RESID_SPLIT, nullptr, 0, dt16, 0};
+            g2.out16 = xlo16; g2.partials = partials_p; g2.ab_tiled = 1;
+            HIPCHK(&c->err, launch_gemm(g2, s));
+        } else
         if (c->split) HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, xn16, rows_g, D, M, VH_EPI_RESID_SPLIT, nullptr, 0, s2));
         else HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, x, rows_g, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0, s2));
         if ((rc = tmark(ST_FC2))) return rc;
@@ -918,8 +940,12 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     size_t w16_bytes = 0;
     auto carve16 = [&](size_t elems) { size_t o = w16_bytes; w16_bytes += align_up(elems * 2, 256); return o; };
     const size_t o_wp = carve16(D * L.KP);
-    std::vector<size_t> o_qkv(cfg->layers), o_o(cfg->layers), o_1(cfg->layers), o_2(cfg->layers);
-    for (int l = 0; l < cfg->layers; ++l) { o_qkv[l] = carve16(3 * D * D); o_o[l] = carve16(D * D); o_1[l] = carve16(M * D); o_2[l] = carve16(D * M); }
+    std::vector<size_t> o_qkv(cfg->layers), o_o(cfg->layers), o_1(cfg->layers), o_2(cfg->layers), o_2t(cfg->layers);
+    const bool want_tiled = cfg->dtype != VH_DTYPE_FP8 && D % 256 == 0 && M % 256 == 0 && !(getenv("VH_H_TILED") && getenv("VH_H_TILED")[0] == '0');
+    for (int l = 0; l < cfg->layers; ++l) {
+        o_qkv[l] = carve16(3 * D * D); o_o[l] = carve16(D * D); o_1[l] = carve16(M * D); o_2[l] = carve16(D * M);
+        o_2t[l] = want_tiled ? carve16(D * M) : 0;
+    }
     const size_t o_bqkv = w16_bytes;
     w16_bytes += align_up((size_t)cfg->layers * 3 * D * 4, 256);
     {
@@ -946,6 +972,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         c->ln_fold_cfg = c->ln_fold;
         c->split_cfg = c->split;
         c->cls_tail = (cfg->flags & VH_FLAG_CLS_TAIL) != 0;
+        c->h_tiled = want_tiled;
         const char* pf = getenv("VH_PATCH_FUSED");
         c->patch_fused = pf && pf[0] == '1';
     }
@@ -961,6 +988,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     for (int l = 0; l < cfg->layers; ++l) {
         c->wqkv16.push_back(c->w16 + o_qkv[l]); c->wo16.push_back(c->w16 + o_o[l]);
         c->w1_16.push_back(c->w16 + o_1[l]); c->w2_16.push_back(c->w16 + o_2[l]);
+        c->w2t_16.push_back(want_tiled ? c->w16 + o_2t[l] : nullptr);
         if (c->fp8) {
             float* sc = (float*)(c->w16 + o_sc) + (size_t)l * sc_per_layer;
             c->sqkv.push_back(sc); c->so.push_back(sc + 3 * D); c->s1.push_back(sc + 4 * D); c->s2.push_back(sc + 4 * D + M);
@@ -1612,6 +1640,11 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
     if (what == 2) {   // how many residual GEMMs of the last forward ran as a split launch (VH_TAIL_OVERLAP)
         if (n_floats != 1) return fail(&c->err, VH_ERR_INVALID, "expected 1 float");
         host_out[0] = (float)c->tail_splits;
+        return VH_OK;
+    }
+    if (what == 3) {   // 1 when the last forward kept the MLP hidden activation in its tiled layout (h_tiled)
+        if (n_floats != 1) return fail(&c->err, VH_ERR_INVALID, "expected 1 float");
+        host_out[0] = c->last_h_tiled ? 1.f : 0.f;
         return VH_OK;
     }
     return fail(&c->err, VH_ERR_INVALID, "unknown tap %d", what);
