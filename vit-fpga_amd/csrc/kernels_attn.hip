@@ -331,7 +331,10 @@ __device__ __forceinline__ void ring_wait_dma() {
 // left every CU half empty for the last quarter of the launch.  The last wave (not a DMA wave) draws the ticket for item
 // i+2 at the top of item i; the result is picked up at the top of item i+1 (vmcnt(8): its stores are younger), handed
 // to the other waves through one LDS word across the item-top barrier, and becomes that item's prefetch target.
-template <typename T, typename TO = T, bool QS = false>
+// OTILE (16-bit results): the output goes to the 16-row-blocked layout [m / 16][D / 8 chunks][16 rows][8 values] that the
+// out-projection's operand DMA reads as 1 KiB of contiguous source per instruction (kernels_gemm5.hip AT): the 32 query rows a
+// half-wave stores per instruction are then two or three contiguous runs of 16-byte pieces instead of 32 pieces a row apart.
+template <typename T, typename TO = T, bool QS = false, bool OTILE = false>
 __global__ void __launch_bounds__(1024, 4)
 attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __restrict__ out,
                       int tokens, int heads, int slabs, int ntiles, int nitems, unsigned int* __restrict__ ticket,
@@ -679,7 +682,11 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
                 // (cdna_hip_programming.md T21): 4 x 16 bytes per lane, half the store instructions for the same bytes --
                 // the phase is store-issue-bound (15 % of a wave's time in r02_c_attn_anatomy.txt).  The swaps run on every
                 // lane (no divergence around a cross-lane instruction); only the stores are predicated.
-                typename TO::elem* const op = out + ((int64_t)b * tokens + (q < tokens ? q : tokens - 1)) * D + h * 64 + 8 * hl;
+                const int64_t mrow = (int64_t)b * tokens + (q < tokens ? q : tokens - 1);
+                // row-major: row mrow, column h * 64 + 8 * hl (+ 32 db + 8 rg); tiled: chunk h * 8 + hl (+ 4 db + rg) of row block mrow >> 4
+                typename TO::elem* const op = OTILE ? out + ((mrow >> 4) * (D >> 3) + h * 8 + hl) * 128 + (mrow & 15) * 8
+                                                    : out + mrow * D + h * 64 + 8 * hl;
+                constexpr int CH = OTILE ? 128 : 8;   // elements from one 8-column chunk to the next
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const f32x16& o = db ? o1 : o0;
@@ -689,7 +696,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
                         const u32x2 gb = __builtin_bit_cast(u32x2, pack4<TO>(o[4 * rg + 4] * inv, o[4 * rg + 5] * inv, o[4 * rg + 6] * inv, o[4 * rg + 7] * inv));
                         const auto sx = __builtin_amdgcn_permlane32_swap(ga[0], gb[0], false, false);
                         const auto sy = __builtin_amdgcn_permlane32_swap(ga[1], gb[1], false, false);
-                        if (q < tokens) *(u32x4*)(op + 32 * db + 8 * rg) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+                        if (q < tokens) *(u32x4*)(op + (4 * db + rg) * CH) = u32x4{sx[0], sy[0], sx[1], sy[1]};
                     }
                 }
             } else {
@@ -742,7 +749,23 @@ extern "C" int vh_diag_attn_read(unsigned long long* host, int n_words) {
 
 size_t attention_lds_bytes(int tokens) { return (size_t)((tokens + 31) / 32) * 8192; }
 
-template <typename T, typename TO = T>
+// which form launch_attn_t picks for (tokens, batch, heads): 2 = staged-Q ring, 1 = ring, 0 = one-shot / persistent double-buffered
+static int attn_form(int batch, int tokens, int heads) {
+    const int ntiles = (tokens + 31) / 32, nqb = ntiles;
+    static const int max_waves = [] { const int e = env_int("VH_ATTN_WAVES", 16); return e < 1 || e > 16 ? 16 : e; }();
+    const int slabs = (nqb + max_waves - 1) / max_waves, nw = (nqb + slabs - 1) / slabs;
+    static const int want_ring = env_int("VH_ATTN_RING", 1);
+    const int G = (tokens + 7) / 8, G2 = (G + 1) & ~1;
+    const size_t qs_lds = (size_t)(G + G2 + 4 * nw) * 1024 + 16;
+    if (attention_lds_bytes(tokens) > 160 * 1024) return -1;
+    if (want_ring >= 1 && want_ring != 2 && slabs == 1 && nw >= 4 && 2 * qs_lds <= 160 * 1024) return 2;
+    if (want_ring && ntiles >= 3 && nw >= 4) return 1;
+    (void)batch; (void)heads;
+    return 0;
+}
+bool attention_tiled_applies(int batch, int tokens, int heads) { return attn_form(batch, tokens, heads) >= 1 && heads % 2 == 0; }
+
+template <typename T, typename TO = T, bool OTILE = false>
 static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, unsigned int* ticket, hipStream_t s, bool tk_zeroed) {
     const int ntiles = (tokens + 31) / 32;
     const int nqb = ntiles;
@@ -767,7 +790,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     const int G = (tokens + 7) / 8, G2 = (G + 1) & ~1;
     const size_t qs_lds = (size_t)(G + G2 + 4 * nw) * 1024 + 16;   // + the ticket word
     if (want_ring >= 1 && want_ring != 2 && slabs == 1 && nw >= 4 && 2 * qs_lds <= 160 * 1024) {
-        auto k = attention_ring_kernel<T, TO, true>;
+        auto k = attention_ring_kernel<T, TO, true, OTILE>;
         static LdsDone lds_done;
         if (hipError_t e = ensure_dynamic_lds((const void*)k, qs_lds, lds_done); e != hipSuccess) return e;
         const int grid = nitems < 2 * num_cu ? nitems : 2 * num_cu;
@@ -780,7 +803,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
         return hipGetLastError();
     }
     if (want_ring && ntiles >= 3 && nw >= 4) {
-        auto k = attention_ring_kernel<T, TO, false>;
+        auto k = attention_ring_kernel<T, TO, false, OTILE>;
         static LdsDone lds_done;
         if (hipError_t e = ensure_dynamic_lds((const void*)k, one, lds_done); e != hipSuccess) return e;
         const int per_cu = (int)(160 * 1024 / one);       // co-resident workgroups per CU by LDS
@@ -790,6 +813,8 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
                            tokens, heads, slabs, ntiles, nitems, (unsigned int*)nullptr, 0u);
         return hipGetLastError();
     }
+    if constexpr (OTILE) return hipErrorInvalidValue;   // the tiled output exists in the ring forms only (attention_tiled_applies)
+    else
     if constexpr (!std::is_same<T, TO>::value) {
         auto k = attention_kernel<T, false, TO>;
         static LdsDone lds_done;
@@ -922,8 +947,13 @@ hipError_t launch_attention_cls(const void* qkv16, int batch, int tokens, int he
 }
 
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype,
-                            unsigned int* ticket, hipStream_t s, bool ticket_zeroed) {
+                            unsigned int* ticket, hipStream_t s, bool ticket_zeroed, bool out_tiled) {
     if (batch <= 0 || tokens <= 0 || heads <= 0) return hipErrorInvalidValue;
+    if (out_tiled) {
+        if (dtype == VH_DTYPE_FP8 || !attention_tiled_applies(batch, tokens, heads)) return hipErrorInvalidValue;
+        return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16, BF16, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed)
+                                      : launch_attn_t<FP16, FP16, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed);
+    }
     if (dtype == VH_DTYPE_FP8) return launch_attn_t<BF16, E4M3>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed);  // bf16 in, e4m3 out
     return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed)
                                   : launch_attn_t<FP16>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed);

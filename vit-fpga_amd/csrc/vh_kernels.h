@@ -71,8 +71,11 @@ constexpr float kAttnQScale = 0.125f * 1.4426950408889634f;
 // ticket: 4 bytes of device scratch owned by the caller's stream (work-queue counter of the staged ring form; zeroed by
 // the launch unless the caller says it already is: a forward zeroes one word per layer with ONE memset), or nullptr for
 // equal static shares per workgroup
+// out_tiled (16-bit results, ring forms: ask attention_tiled_applies): the output in the 16-row-blocked layout the out-projection's
+// tiled operand DMA reads ([rows / 16][dim / 8][16][8], rows = batch * tokens rounded up to 16 by the caller's buffer)
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16,
-                            int dtype, unsigned int* ticket, hipStream_t stream, bool ticket_zeroed = false);
+                            int dtype, unsigned int* ticket, hipStream_t stream, bool ticket_zeroed = false, bool out_tiled = false);
+bool attention_tiled_applies(int batch, int tokens, int heads);
 // class-token query only: out16 [batch][heads * 64] (VH_FLAG_CLS_TAIL); 16-bit dtypes, tokens <= 1024
 hipError_t launch_attention_cls(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype, hipStream_t stream);
 size_t attention_lds_bytes(int tokens);

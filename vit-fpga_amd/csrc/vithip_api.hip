@@ -162,8 +162,9 @@ struct vh_ctx {
     // fc2's weights once more in the 16-row-blocked layout of the tiled hidden activation (h_tiled; 16-bit folded path): the MLP
     // hidden activation then leaves fc1's epilogue straight from the registers (gemm_epilogue.h OTILED) and fc2's operand DMA reads
     // both operands in that layout -- same values, same k order, same bits as the row-major path
-    std::vector<void*> w2t_16;
+    std::vector<void*> w2t_16, wot_16;   // (+ the out-projection's: attention writes its output tiled as well, att_tiled below)
     bool h_tiled = false;     // VH_H_TILED=0 (read when the context is created) keeps the row-major h (A/B, tests)
+    bool att_tiled = true;    // VH_ATT_TILED=0 (read when the context is created) keeps the attention output row-major
     bool weights_ready_tiled = false;   // the tiled copies exist for the CURRENT weights (prepared with the fold on)
     float* bqkv = nullptr;    // [layers, 3D]
     // VH_DTYPE_FP8: the four per-layer matrices hold e4m3 bytes (in the same arena) + one fp32 scale per output channel;
@@ -362,6 +363,7 @@ int prepare_weights(vh_ctx* c) {
         HIPCHK(&c->err, launch_cast(P + o.ow, c->wo16[l], (int64_t)D * D, f.dtype, s));
         HIPCHK(&c->err, launch_cast(P + o.f2w, c->w2_16[l], (int64_t)D * M, f.dtype, s));
         if (c->h_tiled && c->w2t_16[l]) HIPCHK(&c->err, launch_cast_tiled_w(P + o.f2w, D, M, c->w2t_16[l], f.dtype, s));
+        if (c->h_tiled && c->wot_16[l]) HIPCHK(&c->err, launch_cast_tiled_w(P + o.ow, D, D, c->wot_16[l], f.dtype, s));
         if (w8tmp) { HIPCHK(&c->err, hipStreamSynchronize(s)); }   // the scratch is reused by the next layer
     }
     HIPCHK(&c->err, hipStreamSynchronize(s));
@@ -519,6 +521,8 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
                       (size_t)L.NP * L.KP * esz >= 2 * ((size_t)D * esz + 256);
     // tiled hidden activation: both MLP GEMMs must take the persistent form (whole 256-row tiles, enough of them), the 16-bit split path
     const bool h_tiled = c->h_tiled && c->split && !c->fp8 && c->weights_ready_tiled && gemm_tiled_applies(rows_g, M, D) && gemm_tiled_applies(rows_g, D, M);
+    // the attention output likewise (16-bit ring forms -> the out-projection's tiled operand DMA); VH_ATT_TILED=0 keeps it row-major
+    const bool att_tiled = h_tiled && c->att_tiled && gemm_tiled_applies(rows_g, D, D) && attention_tiled_applies(batch, T, f.heads) && !tail;
     c->last_h_tiled = h_tiled && nl > 0 && c->ln_fold;
     for (int l = 0; l < nl && c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
@@ -563,10 +567,15 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
             return VH_OK;
         }
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, tickets_part + l, s, true));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, tickets_part + l, s, true, att_tiled));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
+        if (att_tiled) {
+            GemmArgs go{att16, c->wot_16[l], P + o.ob, xn16, rows_g, D, D, VH_EPI_RESID_SPLIT, nullptr, 0, dt16, 0};
+            go.out16 = xlo16; go.partials = partials_p; go.ab_tiled = 1;
+            HIPCHK(&c->err, launch_gemm(go, s));
+        } else
         if (c->split) HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, xn16, rows_g, D, D, VH_EPI_RESID_SPLIT, nullptr, 0, so));
         else HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows_g, D, D, VH_EPI_RESID_LN, nullptr, 0, so));
         if ((rc = tmark(ST_PROJ))) return rc;
@@ -946,6 +955,8 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         o_qkv[l] = carve16(3 * D * D); o_o[l] = carve16(D * D); o_1[l] = carve16(M * D); o_2[l] = carve16(D * M);
         o_2t[l] = want_tiled ? carve16(D * M) : 0;
     }
+    std::vector<size_t> o_ot(cfg->layers);
+    for (int l = 0; l < cfg->layers; ++l) o_ot[l] = want_tiled ? carve16(D * D) : 0;
     const size_t o_bqkv = w16_bytes;
     w16_bytes += align_up((size_t)cfg->layers * 3 * D * 4, 256);
     {
@@ -973,6 +984,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         c->split_cfg = c->split;
         c->cls_tail = (cfg->flags & VH_FLAG_CLS_TAIL) != 0;
         c->h_tiled = want_tiled;
+        { const char* e = getenv("VH_ATT_TILED"); c->att_tiled = !(e && e[0] == '0'); }
         const char* pf = getenv("VH_PATCH_FUSED");
         c->patch_fused = pf && pf[0] == '1';
     }
@@ -989,6 +1001,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         c->wqkv16.push_back(c->w16 + o_qkv[l]); c->wo16.push_back(c->w16 + o_o[l]);
         c->w1_16.push_back(c->w16 + o_1[l]); c->w2_16.push_back(c->w16 + o_2[l]);
         c->w2t_16.push_back(want_tiled ? c->w16 + o_2t[l] : nullptr);
+        c->wot_16.push_back(want_tiled ? c->w16 + o_ot[l] : nullptr);
         if (c->fp8) {
             float* sc = (float*)(c->w16 + o_sc) + (size_t)l * sc_per_layer;
             c->sqkv.push_back(sc); c->so.push_back(sc + 3 * D); c->s1.push_back(sc + 4 * D); c->s2.push_back(sc + 4 * D + M);
