@@ -261,7 +261,9 @@ int vh_get_step_timing(vh_ctx* ctx, double* step_ms, int max_steps, int* steps);
  *       3 = one float: 1 when the last forward kept the MLP hidden activation in its tiled (16-row-blocked) layout -- the
  *           default wherever both MLP GEMMs take the persistent form (16-bit folded path, whole 256-row tiles; VH_H_TILED=0 at
  *           context creation keeps it row-major): same values, same logit bits, fc1's result leaves the registers without an
- *           LDS transposition. */
+ *           LDS transposition,
+ *       4 = one float: 1 when the last forward kept q|k|v head-major ([3][heads][rows][64]) between the projection's epilogue
+ *           and the attention kernel (default where the attention output is tiled; VH_QKV_HM=0 keeps [rows][3 D]; same bits). */
 int vh_debug_read(vh_ctx* ctx, int what, float* host_out, size_t n_floats);
 /* run only the first `n_layers` encoder layers on the next forwards (-1 = all) */
 int vh_debug_set_layers(vh_ctx* ctx, int n_layers);

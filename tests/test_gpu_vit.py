@@ -143,28 +143,32 @@ def test_patch_embedding_with_the_gather_inside_the_gemm_gives_the_same_bits(mon
 def test_tiled_hidden_activation_gives_the_same_bits_as_the_row_major_one(monkeypatch, name, batch, dtype_name):
     """Round 4: where both MLP GEMMs take the persistent form, fc1 writes the hidden activation h in a 16-row-blocked layout
     straight from its registers (no LDS transposition) and fc2's operand DMA reads h and a tiled copy of its weights in that
-    layout; the attention kernel writes its output in the same layout for the out-projection (VH_ATT_TILED).  Natural column order
+    layout; the attention kernel writes its output in the same layout for the out-projection (VH_ATT_TILED), and reads q|k|v
+    HEAD-MAJOR ([3][heads][rows][64]) as the projection's epilogue then writes it (VH_QKV_HM).  Natural column order
     inside every chunk, so every MFMA sees the same k order: the logits must equal the row-major path's bit for bit (VH_H_TILED=0)
     -- on exact tiles (batch 256), on rows padded to whole tiles (300) and on ViT-L (T = 577: the ring without Q staging)."""
     cfg = S.CONFIGS[name]
     dt = {"bf16": vithip.DTYPE_BF16, "fp16": vithip.DTYPE_FP16}[dtype_name]
     px = cfg["image_size"] ** 2 * cfg["channels"]
     din, dout = vithip.DeviceBuffer(batch * px * 4), vithip.DeviceBuffer(batch * cfg["classes"] * 4)
-    outs, used = [], []
-    for tiled, att in (("0", "1"), ("1", "0"), ("1", "1")):   # row-major; h tiled only; h and the attention output tiled (the default)
+    outs, used, used_hm = [], [], []
+    # row-major; h tiled only; h and the attention output tiled; q|k|v head-major as well (the default)
+    for tiled, att, hm in (("0", "1", "1"), ("1", "0", "1"), ("1", "1", "0"), ("1", "1", "1")):
         monkeypatch.setenv("VH_H_TILED", tiled)
         monkeypatch.setenv("VH_ATT_TILED", att)
+        monkeypatch.setenv("VH_QKV_HM", hm)
         ctx = vithip.VitContext(cfg, dtype=dt, max_batch=batch)
         ctx.init_weights_seeded(0)
         ctx.fill_input_seeded(1, batch, din.ptr)
         ctx.forward_device(din.ptr, batch, dout.ptr)
         outs.append(dout.to_numpy(np.float32, (batch, cfg["classes"])))
         used.append(int(ctx.debug_read(3, 1)[0]))
+        used_hm.append(int(ctx.debug_read(4, 1)[0]))
         small = ctx.forward(din.to_numpy(np.float32, (batch, cfg["image_size"], cfg["image_size"], cfg["channels"]))[:2])   # a batch too small for the persistent form
         assert int(ctx.debug_read(3, 1)[0]) == 0 and np.array_equal(small, outs[-1][:2])
         ctx.close()
-    assert used == [0, 1, 1], used
-    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert used == [0, 1, 1, 1] and used_hm == [0, 0, 0, 1], (used, used_hm)
+    assert np.isfinite(outs[0]).all() and all(np.array_equal(outs[0], o) for o in outs[1:])
 
 
 def test_layernorm_fold_is_a_property_of_the_configuration_not_of_the_workspace_size():

@@ -349,6 +349,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 const int n = n_w + ((pc ^ (r & 7)) << 3);
                 const int m = m_w + h * SMI * 16 + r;
                 if constexpr (VH_EPI_ABL & 16) asm volatile("" :: "v"(v));
+                else if constexpr (OTILED) {
+                    // q|k|v HEAD-MAJOR, [N / 64][M][64] (round 4; whole tiles): the wave's 64 columns are one head's q, k or v, whose rows
+                    // then lie 128 B apart -- this store instruction writes 1 KiB of contiguous memory (8 rows), and attention's operand
+                    // DMA reads it the same way (kernels_attn.hip IHM).  Same values, another address.
+                    epi_store(v, (u32x4*)((elem*)e.out + ((int64_t)(n_w >> 6) * M + m) * 64 + ((pc ^ (r & 7)) << 3)));
+                }
                 else if (MFULL || m < M) epi_store(v, (u32x4*)((elem*)e.out + (int64_t)m * N + n));
             }
         }

@@ -334,11 +334,14 @@ __device__ __forceinline__ void ring_wait_dma() {
 // OTILE (16-bit results): the output goes to the 16-row-blocked layout [m / 16][D / 8 chunks][16 rows][8 values] that the
 // out-projection's operand DMA reads as 1 KiB of contiguous source per instruction (kernels_gemm5.hip AT): the 32 query rows a
 // half-wave stores per instruction are then two or three contiguous runs of 16-byte pieces instead of 32 pieces a row apart.
-template <typename T, typename TO = T, bool QS = false, bool OTILE = false>
+// IHM (round 4): q|k|v arrives HEAD-MAJOR, [3][heads][hm_rows][64] -- the projection's epilogue writes it so (gemm_epilogue.h: a
+// wave's 64 output columns are exactly one head's q, k or v) -- instead of [rows][3 * heads * 64]: a head's rows are 128 B apart,
+// so every DMA piece (8 rows) is ONE KiB of contiguous source instead of eight 128-byte segments 3 * D * 2 bytes apart.
+template <typename T, typename TO = T, bool QS = false, bool OTILE = false, bool IHM = false>
 __global__ void __launch_bounds__(1024, 4)
 attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::elem* __restrict__ out,
                       int tokens, int heads, int slabs, int ntiles, int nitems, unsigned int* __restrict__ ticket,
-                      unsigned int heads_rcp) {
+                      unsigned int heads_rcp, int64_t hm_rows) {
     using elem = typename T::elem;
     using vec8 = typename T::vec8;
     using vec4 = typename T::vec4;
@@ -357,17 +360,23 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
     const int nw = blockDim.x >> 6;
     const int l31 = lane & 31, hl = lane >> 5;
     const int D = heads * 64;
-    const int64_t ld = 3 * (int64_t)D;
+    const int64_t ld = IHM ? 64 : 3 * (int64_t)D;
+    // byte offset of the K plane behind the Q plane (V: twice that): the next D columns of the row, or the next `heads` head blocks
+    const uint32_t koff2 = IHM ? (uint32_t)(hm_rows * D * 2) : (uint32_t)(D * 2);
+    auto head_base = [&](int b, int h) {
+        if constexpr (IHM) return qkv + ((int64_t)h * hm_rows + (int64_t)b * tokens) * 64;
+        else return qkv + (int64_t)b * tokens * ld + h * 64;
+    };
 
     // ---- DMA of one key tile (32 rows of K and of V = 8 pieces of 1 KiB): waves 0-3 move one K and one V piece each
     auto kv_base = [&](int item) {
         if (QS) {   // one slab; b = item / heads by the host's reciprocal ceil(2^32 / heads) (exact for item * heads < 2^32; heads == 1 has no 32-bit reciprocal)
             const int b = (heads == 1 ? item : (int)__umulhi((unsigned)item, heads_rcp)), h = item - b * heads;
-            return qkv + (int64_t)b * tokens * ld + h * 64;
+            return head_base(b, h);
         }
         const int bh = item / slabs;
         const int b = bh / heads, h = bh - b * heads;
-        return qkv + (int64_t)b * tokens * ld + h * 64;
+        return head_base(b, h);
     };
     // Source address = wave-uniform base (scalar registers) + a 32-bit per-lane byte offset that is recomputed from the
     // lane id at every issue (the id is laundered so that the compiler cannot hoist twelve address registers out of
@@ -384,8 +393,8 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
         const int rv = rowv < tokens ? rowv : tokens - 1;
         const int ck = pc_ ^ ((rowk >> 1) & 7);
         const int cv = pc_ ^ (((rowv >> 1) & 1) << 2);
-        const uint32_t ok = (uint32_t)(rk * (int)ld + D + ck * 8) * 2u;
-        const uint32_t ov = (uint32_t)(rv * (int)ld + 2 * D + cv * 8) * 2u;
+        const uint32_t ok = (uint32_t)(rk * (int)ld + ck * 8) * 2u + koff2;
+        const uint32_t ov = (uint32_t)(rv * (int)ld + cv * 8) * 2u + 2u * koff2;
         ring_dma16(base, ok, lds0 + gk * 1024);
         ring_dma16(base, ov, lds0 + kv_bytes + gv * 1024);
     };
@@ -407,7 +416,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
         const int b = bh / heads, h = bh - b * heads;
         int qrow = (slab * nw + wave) * 32 + l31;
         qrow = qrow < tokens ? qrow : tokens - 1;
-        const elem* qp = qkv + ((int64_t)b * tokens + qrow) * ld + h * 64 + 8 * hl;
+        const elem* qp = head_base(b, h) + (int64_t)qrow * ld + 8 * hl;
         // Inline asm, in place: the item-top wait leaves the 8 output stores issued behind these loads in flight
         // (vmcnt(8)), which hipcc's own accounting for an ordinary load cannot express across the predicated store block
         // (it falls back to vmcnt(0) = wait for the stores just issued, every item).  ring_wait_item() orders the uses.
@@ -765,8 +774,9 @@ static int attn_form(int batch, int tokens, int heads) {
 }
 bool attention_tiled_applies(int batch, int tokens, int heads) { return attn_form(batch, tokens, heads) >= 1 && heads % 2 == 0; }
 
-template <typename T, typename TO = T, bool OTILE = false>
-static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, unsigned int* ticket, hipStream_t s, bool tk_zeroed) {
+template <typename T, typename TO = T, bool OTILE = false, bool IHM = false>
+static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int heads, void* out, unsigned int* ticket, hipStream_t s, bool tk_zeroed,
+                                int64_t hm_rows = 0) {
     const int ntiles = (tokens + 31) / 32;
     const int nqb = ntiles;
     // waves per workgroup (each owns 32 queries): VH_ATTN_WAVES, default 16 (T = 577: 10 waves share one K/V image instead of 7)
@@ -790,7 +800,7 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
     const int G = (tokens + 7) / 8, G2 = (G + 1) & ~1;
     const size_t qs_lds = (size_t)(G + G2 + 4 * nw) * 1024 + 16;   // + the ticket word
     if (want_ring >= 1 && want_ring != 2 && slabs == 1 && nw >= 4 && 2 * qs_lds <= 160 * 1024) {
-        auto k = attention_ring_kernel<T, TO, true, OTILE>;
+        auto k = attention_ring_kernel<T, TO, true, OTILE, IHM>;
         static LdsDone lds_done;
         if (hipError_t e = ensure_dynamic_lds((const void*)k, qs_lds, lds_done); e != hipSuccess) return e;
         const int grid = nitems < 2 * num_cu ? nitems : 2 * num_cu;
@@ -799,18 +809,18 @@ static hipError_t launch_attn_t(const void* qkv, int batch, int tokens, int head
         if (tk && !tk_zeroed) { if (hipError_t e = hipMemsetAsync(tk, 0, sizeof(unsigned int), s); e != hipSuccess) return e; }
         const unsigned int heads_rcp = (unsigned int)(((1ull << 32) + (unsigned)heads - 1) / (unsigned)heads);
         hipLaunchKernelGGL(k, dim3(grid), dim3(nw * 64), qs_lds, s, (const typename T::elem*)qkv, (typename TO::elem*)out,
-                           tokens, heads, slabs, ntiles, nitems, tk, heads_rcp);
+                           tokens, heads, slabs, ntiles, nitems, tk, heads_rcp, hm_rows);
         return hipGetLastError();
     }
     if (want_ring && ntiles >= 3 && nw >= 4) {
-        auto k = attention_ring_kernel<T, TO, false, OTILE>;
+        auto k = attention_ring_kernel<T, TO, false, OTILE, IHM>;
         static LdsDone lds_done;
         if (hipError_t e = ensure_dynamic_lds((const void*)k, one, lds_done); e != hipSuccess) return e;
         const int per_cu = (int)(160 * 1024 / one);       // co-resident workgroups per CU by LDS
         int grid = num_cu * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
         if (grid > batch * heads) grid = batch * heads;   // a workgroup walks heads; the slabs of a head share its K/V image
         hipLaunchKernelGGL(k, dim3(grid), dim3(nw * 64), one, s, (const typename T::elem*)qkv, (typename TO::elem*)out,
-                           tokens, heads, slabs, ntiles, nitems, (unsigned int*)nullptr, 0u);
+                           tokens, heads, slabs, ntiles, nitems, (unsigned int*)nullptr, 0u, hm_rows);
         return hipGetLastError();
     }
     if constexpr (OTILE) return hipErrorInvalidValue;   // the tiled output exists in the ring forms only (attention_tiled_applies)
@@ -947,8 +957,14 @@ hipError_t launch_attention_cls(const void* qkv16, int batch, int tokens, int he
 }
 
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype,
-                            unsigned int* ticket, hipStream_t s, bool ticket_zeroed, bool out_tiled) {
+                            unsigned int* ticket, hipStream_t s, bool ticket_zeroed, bool out_tiled, int64_t in_hm_rows) {
     if (batch <= 0 || tokens <= 0 || heads <= 0) return hipErrorInvalidValue;
+    if (in_hm_rows) {   // head-major q|k|v [3][heads][in_hm_rows][64] (the persistent projection's layout): ring forms with the tiled output only
+        if (!out_tiled || in_hm_rows < (int64_t)batch * tokens || in_hm_rows * heads * 64 * 4 >= (1ll << 32)) return hipErrorInvalidValue;
+        if (dtype == VH_DTYPE_FP8 || !attention_tiled_applies(batch, tokens, heads)) return hipErrorInvalidValue;
+        return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16, BF16, true, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed, in_hm_rows)
+                                      : launch_attn_t<FP16, FP16, true, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed, in_hm_rows);
+    }
     if (out_tiled) {
         if (dtype == VH_DTYPE_FP8 || !attention_tiled_applies(batch, tokens, heads)) return hipErrorInvalidValue;
         return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16, BF16, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed)

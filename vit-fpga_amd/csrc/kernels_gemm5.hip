@@ -578,7 +578,8 @@ static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
             const int num_cu = device_num_cu();   // of the device this launch goes to (a group has one thread per device)
             if (!num_cu) return hipErrorUnknown;
             const int nfull = full_m * tiles_n;
-            if constexpr (!F8 && (EPI == VH_EPI_LNFOLD_GELU || EPI == VH_EPI_BIAS_GELU)) {
+            // (LNFOLD / BIAS with out_tiled: the q|k|v projection's HEAD-MAJOR result, gemm_epilogue.h)
+            if constexpr (!F8 && (EPI == VH_EPI_LNFOLD_GELU || EPI == VH_EPI_BIAS_GELU || EPI == VH_EPI_LNFOLD || EPI == VH_EPI_BIAS)) {
                 if (g.out_tiled) return g.ab_tiled ? hipErrorInvalidValue : launch_pp_one<T, EPI, F8, true, 2, true, false>(g, nfull < num_cu ? nfull : num_cu, full_m, tiles_n, s);
             }
             if constexpr (!F8 && (EPI == VH_EPI_RESID_SPLIT || EPI == VH_EPI_BIAS)) {

@@ -74,7 +74,8 @@ constexpr float kAttnQScale = 0.125f * 1.4426950408889634f;
 // out_tiled (16-bit results, ring forms: ask attention_tiled_applies): the output in the 16-row-blocked layout the out-projection's
 // tiled operand DMA reads ([rows / 16][dim / 8][16][8], rows = batch * tokens rounded up to 16 by the caller's buffer)
 hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads, void* out16,
-                            int dtype, unsigned int* ticket, hipStream_t stream, bool ticket_zeroed = false, bool out_tiled = false);
+                            int dtype, unsigned int* ticket, hipStream_t stream, bool ticket_zeroed = false, bool out_tiled = false,
+                            int64_t in_hm_rows = 0);   // in_hm_rows != 0: q|k|v is head-major, [3][heads][in_hm_rows][64] (needs out_tiled)
 bool attention_tiled_applies(int batch, int tokens, int heads);
 // class-token query only: out16 [batch][heads * 64] (VH_FLAG_CLS_TAIL); 16-bit dtypes, tokens <= 1024
 hipError_t launch_attention_cls(const void* qkv16, int batch, int tokens, int heads, void* out16, int dtype, hipStream_t stream);

@@ -165,6 +165,7 @@ struct vh_ctx {
     std::vector<void*> w2t_16, wot_16;   // (+ the out-projection's: attention writes its output tiled as well, att_tiled below)
     bool h_tiled = false;     // VH_H_TILED=0 (read when the context is created) keeps the row-major h (A/B, tests)
     bool att_tiled = true;    // VH_ATT_TILED=0 (read when the context is created) keeps the attention output row-major
+    bool qkv_hm = true;       // VH_QKV_HM=0 keeps q|k|v row-major ([rows][3 D]) instead of head-major ([3][heads][rows][64]; needs att_tiled)
     bool weights_ready_tiled = false;   // the tiled copies exist for the CURRENT weights (prepared with the fold on)
     float* bqkv = nullptr;    // [layers, 3D]
     // VH_DTYPE_FP8: the four per-layer matrices hold e4m3 bytes (in the same arena) + one fp32 scale per output channel;
@@ -226,6 +227,7 @@ struct vh_ctx {
     hipEvent_t ev_tail_a = nullptr, ev_tail_l = nullptr;
     bool tail_overlap = false;
     bool last_h_tiled = false;   // debug tap 3
+    bool last_qkv_hm = false;    // debug tap 4
     int tail_splits = 0;   // residual GEMMs of the last forward that were launched as [full rounds] + [tail round] (debug tap 2)
     int num_cu = 256;
     // optional hipGraph replay of the forward's launch sequence (vh_set_graph): one instantiated graph per
@@ -523,7 +525,10 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     const bool h_tiled = c->h_tiled && c->split && !c->fp8 && c->weights_ready_tiled && gemm_tiled_applies(rows_g, M, D) && gemm_tiled_applies(rows_g, D, M);
     // the attention output likewise (16-bit ring forms -> the out-projection's tiled operand DMA); VH_ATT_TILED=0 keeps it row-major
     const bool att_tiled = h_tiled && c->att_tiled && gemm_tiled_applies(rows_g, D, D) && attention_tiled_applies(batch, T, f.heads) && !tail;
+    // q|k|v head-major between the projection's epilogue and attention's operand DMA (same condition + the persistent form for N = 3 D)
+    const bool qkv_hm = att_tiled && c->qkv_hm && gemm_tiled_applies(rows_g, 3 * D, D);
     c->last_h_tiled = h_tiled && nl > 0 && c->ln_fold;
+    c->last_qkv_hm = qkv_hm && nl > 0 && c->ln_fold;
     for (int l = 0; l < nl && c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
         const float* cd = c->fold_cd + (size_t)l * (6 * D + 2 * M);
@@ -531,6 +536,11 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         if ((rc = tmark(ST_QKV))) return rc;
         const float *sq = c->fp8 ? c->sqkv[l] : nullptr, *so = c->fp8 ? c->so[l] : nullptr;
         const float *s1 = c->fp8 ? c->s1[l] : nullptr, *s2 = c->fp8 ? c->s2[l] : nullptr;
+        if (qkv_hm) {
+            GemmArgs gq{xn16, c->wqkv16[l], cd + 3 * D, qkv16, rows_g, 3 * D, D, VH_EPI_LNFOLD, cd, 0, dt16, 0};
+            gq.stats = stats_p; gq.out_tiled = 1;
+            HIPCHK(&c->err, launch_gemm(gq, s));
+        } else
         HIPCHK(&c->err, gemm(xn16, c->wqkv16[l], cd + 3 * D, qkv16, rows_g, 3 * D, D, VH_EPI_LNFOLD, cd, 0, sq));
         if ((rc = tmark(ST_QKV))) return rc;
         if ((rc = mark(ST_QKV))) return rc;
@@ -567,7 +577,8 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
             return VH_OK;
         }
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, tickets_part + l, s, true, att_tiled));
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, tickets_part + l, s, true, att_tiled,
+                                         qkv_hm ? (int64_t)rows_g : 0));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
         if ((rc = tmark(ST_PROJ))) return rc;
@@ -985,6 +996,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         c->cls_tail = (cfg->flags & VH_FLAG_CLS_TAIL) != 0;
         c->h_tiled = want_tiled;
         { const char* e = getenv("VH_ATT_TILED"); c->att_tiled = !(e && e[0] == '0'); }
+        { const char* e = getenv("VH_QKV_HM"); c->qkv_hm = !(e && e[0] == '0'); }
         const char* pf = getenv("VH_PATCH_FUSED");
         c->patch_fused = pf && pf[0] == '1';
     }
@@ -1658,6 +1670,11 @@ int vh_debug_read(vh_ctx* c, int what, float* host_out, size_t n_floats) {
     if (what == 3) {   // 1 when the last forward kept the MLP hidden activation in its tiled layout (h_tiled)
         if (n_floats != 1) return fail(&c->err, VH_ERR_INVALID, "expected 1 float");
         host_out[0] = c->last_h_tiled ? 1.f : 0.f;
+        return VH_OK;
+    }
+    if (what == 4) {   // 1 when the last forward kept q|k|v head-major (qkv_hm)
+        if (n_floats != 1) return fail(&c->err, VH_ERR_INVALID, "expected 1 float");
+        host_out[0] = c->last_qkv_hm ? 1.f : 0.f;
         return VH_OK;
     }
     return fail(&c->err, VH_ERR_INVALID, "unknown tap %d", what);
