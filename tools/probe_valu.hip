@@ -27,17 +27,29 @@
 #define I_MAX16(i) "v_pk_max_f16 %" #i ", %8, %" #i "\n\t"
 #define I_FP8(i) "v_cvt_pk_fp8_f32 %" #i ", %8, %9\n\t"
 
+// dependency distance: the same 32 packed fmas per body on 1, 2 or 4 register chains instead of 8 (round 4, after the evidence
+// set: the GELU polynomial of the fc1 epilogue advances TWO chains in alternation -- what does a wave pay for that?)
+#define REP8_C1(X) X(0) X(0) X(0) X(0) X(0) X(0) X(0) X(0)
+#define REP8_C2(X) X(0) X(1) X(0) X(1) X(0) X(1) X(0) X(1)
+#define REP8_C4(X) X(0) X(1) X(2) X(3) X(0) X(1) X(2) X(3)
+#define BODY4_C1(X) REP8_C1(X) REP8_C1(X) REP8_C1(X) REP8_C1(X)
+#define BODY4_C2(X) REP8_C2(X) REP8_C2(X) REP8_C2(X) REP8_C2(X)
+#define BODY4_C4(X) REP8_C4(X) REP8_C4(X) REP8_C4(X) REP8_C4(X)
+
 template <int KIND>
 __global__ void __launch_bounds__(1024) probe(unsigned long long* out, float seed) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     unsigned long long t0, t1;
     const float s = seed + (float)threadIdx.x * 1e-6f;
-    if constexpr (KIND == 1 || KIND == 9 || KIND == 10) {   // 64-bit operands
+    if constexpr (KIND == 1 || KIND == 9 || KIND == 10 || KIND >= 20) {   // 64-bit operands
         f32x2 a0{s, s}, a1{s, s}, a2{s, s}, a3{s, s}, a4{s, s}, a5{s, s}, a6{s, s}, a7{s, s}, b{0.999f, 0.999f}, c{1e-3f, 1e-3f};
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
         for (int r = 0; r < 256; ++r) {
             if constexpr (KIND == 1) asm volatile(BODY4(I_PKFMA32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
             if constexpr (KIND == 9) asm volatile(BODY4(I_PKADD32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            if constexpr (KIND == 20) asm volatile(BODY4_C1(I_PKFMA32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            if constexpr (KIND == 21) asm volatile(BODY4_C2(I_PKFMA32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            if constexpr (KIND == 22) asm volatile(BODY4_C4(I_PKFMA32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
             if constexpr (KIND == 10) asm volatile(BODY4(I_PKMUL32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
         }
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -82,6 +94,9 @@ int main() {
     printf("cycles per wave64 instruction as one wave sees it (and, in brackets, per instruction as the SIMD sees it)\n");
     run<0>("v_fma_f32", d);
     run<1>("v_pk_fma_f32", d);
+    run<20>("v_pk_fma_f32, 1 chain", d);
+    run<21>("v_pk_fma_f32, 2 chains", d);
+    run<22>("v_pk_fma_f32, 4 chains", d);
     run<9>("v_pk_add_f32", d);
     run<10>("v_pk_mul_f32", d);
     run<2>("v_pk_fma_f16", d);
