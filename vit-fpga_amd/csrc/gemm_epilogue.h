@@ -610,7 +610,12 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const 
 // A lane's accumulator quad is 4 consecutive columns = one dword of e4m3.  Staged like the 16-bit form: the
 // wave's 64-column rows are 64 B = 4 chunks of 16 B, chunk c of row r at position c ^ ((r >> 1) & 3); read back
 // 16 B per lane, 4 lanes per row, and stored as whole 64-B row segments.  Ragged tiles store dwords directly.
-template <int EPI, int MI, int NI, int SMI, bool MFULL = false>
+// OTILED (whole tiles): the e4m3 hidden activation in the tiled layout of the e4m3 A operand, [m / 16][N / 16 chunks][16 rows][16 B]
+// (a chunk = 16 k-bytes: the same 2 KiB per row block and K-tile as the 16-bit layout).  A lane holds one dword (4 columns) of each
+// of the wave's four 16-column blocks; a 4 x 4 transpose over the four 16-lane rows -- two v_permlane32_swap, two
+// v_permlane16_swap -- leaves the lanes of row q with the 16 consecutive bytes of block q: one 16-byte store per lane, 1 KiB of
+// contiguous memory per instruction, no LDS staging.
+template <int EPI, int MI, int NI, int SMI, bool MFULL = false, bool OTILED = false>
 __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w, int lane,
                                                bool n_full, char* smem, int wave) {
     static_assert(NI == 4 && MI % SMI == 0, "64-column wave tile");
@@ -639,6 +644,25 @@ __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const
                 m = m < M ? m : M - 1;
                 lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
             }
+        }
+        if constexpr (OTILED && MFULL) {
+            uint8_t* const obase = out + ((int64_t)(m_w >> 4) * (N >> 4) + (n_w >> 4) + fq) * 256 + frow * 16;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                uint32_t x[NI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (epi_is_lnfold(EPI)) x[ni] = value(acc[mi][ni], bv[ni], cv[ni], lnst[mi].x * lnst[mi].y, lnst[mi].y);
+                    else x[ni] = value(acc[mi][ni], bv[ni]);
+                }
+                // halves first (rows 2, 3 of x0 / x1 <-> rows 0, 1 of x2 / x3), then odd / even rows inside the halves
+                const auto a = __builtin_amdgcn_permlane32_swap(x[0], x[2], false, false);
+                const auto b = __builtin_amdgcn_permlane32_swap(x[1], x[3], false, false);
+                const auto lo = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                epi_store(u32x4{lo[0], lo[1], hi[0], hi[1]}, (u32x4*)(obase + (int64_t)mi * (N >> 4) * 256));
+            }
+            return;
         }
         char* sw = smem + wave * (SMI * 16 * 128);
         const int rr = lane >> 2, pc = lane & 3;

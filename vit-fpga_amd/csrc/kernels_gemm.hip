@@ -199,6 +199,10 @@ bool gemm_tiled_applies(int64_t M, int N, int K) {
     return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K / 64 >= 2 && gemm_pick_variant(M, N, VH_EPI_BIAS) == 6;
 }
 
+bool gemm_tiled_applies_f8(int64_t M, int N, int K) {   // (launch_gemm_fp8 takes the persistent form whenever whole tiles allow it)
+    return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && K / 128 >= 2 && gemm_pp_variant(VH_EPI_BIAS) == 6;
+}
+
 const char* gemm_check(const GemmArgs& g) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return "gemm: empty shape";
     if (g.K % 64) return "gemm: K must be a multiple of 64";

@@ -143,7 +143,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
 #endif
     constexpr int BM = 256, BN = 256;
     constexpr int KT_BYTES = 128;                  // one K-tile row: 64 16-bit or 128 8-bit elements
-    static_assert(!(OT || AT) || (PERSIST && !F8), "tiled layouts: persistent 16-bit form only");
+    static_assert(!(OT || AT) || PERSIST, "tiled layouts: persistent form only");
     constexpr int KT_STEP = AT ? 2048 : KT_BYTES;  // source bytes from one K-tile to the next (tiled: 8 chunks x 256 B)
     constexpr int STAGE_BYTES = 65536, W_OFF = 32768;
     // AST = number of LDS stages of the A (activation) operand.  2: stage s = [A 32 KiB | W 32 KiB] at s * 64 KiB.
@@ -235,8 +235,8 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     const int frow = lane & 15, fq = lane >> 4;
     // 16-bit: k-step 0 / 1 = chunk fq / 4+fq; fp8: the lane's 32 k-bytes = chunks 2fq and 2fq+1
     // (AT: row block = 8 chunks x [16 rows x 16 B]; a fragment read takes 4 chunks x 16 rows = 1 KiB of contiguous LDS: no swizzle needed)
-    const int off0 = AT ? fq * 256 + frow * 16 : frow * 128 + (((F8 ? 2 * fq : fq) ^ (frow & 7)) << 4);
-    const int off1 = AT ? (4 + fq) * 256 + frow * 16 : frow * 128 + (((F8 ? 2 * fq + 1 : 4 | fq) ^ (frow & 7)) << 4);
+    const int off0 = AT ? (F8 ? 2 * fq : fq) * 256 + frow * 16 : frow * 128 + (((F8 ? 2 * fq : fq) ^ (frow & 7)) << 4);
+    const int off1 = AT ? (F8 ? 2 * fq + 1 : 4 + fq) * 256 + frow * 16 : frow * 128 + (((F8 ? 2 * fq + 1 : 4 | fq) ^ (frow & 7)) << 4);
     const int xbase = grp * 16384;          // rows 128*grp ..  (inside an A stage)
     const int wbase = wn * 8192;            // rows 64*wn ..    (inside a W stage)
 
@@ -471,7 +471,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // fp8 operands: GELU results leave as e4m3 (the next GEMM's A operand); RESID_LN writes an e4m3 copy of the rows, RESID_SPLIT
             // keeps the residual itself as an e4m3 plane (that operand) + a bf16 plane
             if constexpr (F8 && epi_has_gelu(EPI))
-                gemm_epilogue8<EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, true, stage_epi, wave);
+                gemm_epilogue8<EPI, MI, NI, VH_PP_SMI, true, OT>(acc, e, m_w, n_w, lane_e, true, stage_epi, wave);
             else if constexpr (F8 && (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT))
                 gemm_epilogue_staged<E4M3, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
             else
@@ -573,16 +573,17 @@ static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
         // CUs while the rest idle (batch 128: fc2 2.74 ms per forward against 1.96 ms in the one-tile form).  The
         // persistent form gains ~3 %, so it is worth that only when forced (variant 6 asked for explicitly).
         if (mode == 1 && full_m != tiles_m && g.variant != 6) mode = 0;
-        if ((g.out_tiled || g.ab_tiled) && (mode != 1 || full_m != tiles_m || F8)) return hipErrorInvalidValue;   // tiled layouts: persistent 16-bit form on whole tiles only
+        if ((g.out_tiled || g.ab_tiled) && (mode != 1 || full_m != tiles_m)) return hipErrorInvalidValue;   // tiled layouts: persistent form on whole tiles only
         if (mode == 1) {
             const int num_cu = device_num_cu();   // of the device this launch goes to (a group has one thread per device)
             if (!num_cu) return hipErrorUnknown;
             const int nfull = full_m * tiles_n;
             // (LNFOLD / BIAS with out_tiled: the q|k|v projection's HEAD-MAJOR result, gemm_epilogue.h)
-            if constexpr (!F8 && (EPI == VH_EPI_LNFOLD_GELU || EPI == VH_EPI_BIAS_GELU || EPI == VH_EPI_LNFOLD || EPI == VH_EPI_BIAS)) {
+            // (e4m3 operands: the GELU forms write the tiled e4m3 hidden activation, RESID_SPLIT reads it; no head-major q|k|v there)
+            if constexpr (F8 ? (EPI == VH_EPI_LNFOLD_GELU || EPI == VH_EPI_BIAS_GELU) : (EPI == VH_EPI_LNFOLD_GELU || EPI == VH_EPI_BIAS_GELU || EPI == VH_EPI_LNFOLD || EPI == VH_EPI_BIAS)) {
                 if (g.out_tiled) return g.ab_tiled ? hipErrorInvalidValue : launch_pp_one<T, EPI, F8, true, 2, true, false>(g, nfull < num_cu ? nfull : num_cu, full_m, tiles_n, s);
             }
-            if constexpr (!F8 && (EPI == VH_EPI_RESID_SPLIT || EPI == VH_EPI_BIAS)) {
+            if constexpr (F8 ? EPI == VH_EPI_RESID_SPLIT : (EPI == VH_EPI_RESID_SPLIT || EPI == VH_EPI_BIAS)) {
                 if (g.ab_tiled) return g.out_tiled ? hipErrorInvalidValue : launch_pp_one<T, EPI, F8, true, 2, false, true>(g, nfull < num_cu ? nfull : num_cu, full_m, tiles_n, s);
             }
             if (g.out_tiled || g.ab_tiled) return hipErrorInvalidValue;

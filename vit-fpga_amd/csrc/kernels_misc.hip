@@ -208,6 +208,26 @@ hipError_t launch_cast_tiled_w(const float* w, int rows, int cols, void* w16, in
     return hipGetLastError();
 }
 
+// e4m3 weights (one byte per element, rows of `cols` bytes) once more in the tiled layout of the e4m3 operand:
+// [rows / 16][cols / 16 chunks][16 rows][16 B] -- a copy of 16-byte pieces, nothing is converted
+__global__ void __launch_bounds__(256) tile_bytes_kernel(const u32x4* __restrict__ w, u32x4* __restrict__ out, int rows, int cols) {
+    const int cpr = cols >> 4;   // chunks per row
+    const int64_t nchunk = (int64_t)rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r16 = (int)(i & 15);
+        const int64_t bc = i >> 4;                        // block * cpr + chunk
+        const int chunk = (int)(bc % cpr), block = (int)(bc / cpr);
+        out[i] = w[(int64_t)(block * 16 + r16) * cpr + chunk];
+    }
+}
+hipError_t launch_tile_bytes(const void* w8, int rows, int cols, void* out, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || (rows & 15) || (cols & 15)) return hipErrorInvalidValue;
+    const int64_t nchunk = (int64_t)rows * (cols >> 4);
+    const unsigned grid = (unsigned)((nchunk + 255) / 256 < 8192 ? (nchunk + 255) / 256 : 8192);
+    hipLaunchKernelGGL(tile_bytes_kernel, dim3(grid), dim3(256), 0, s, (const u32x4*)w8, (u32x4*)out, rows, cols);
+    return hipGetLastError();
+}
+
 // ---- synthetic data ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ out, int64_t n, uint64_t stream, int kind,
                                                    double scale, float offset) {

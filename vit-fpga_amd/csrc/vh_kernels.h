@@ -40,6 +40,9 @@ struct GemmArgs {
 bool gemm_tiled_applies(int64_t M, int N, int K);
 // W fp32 [rows, cols] -> 16-bit in the tiled layout (16-row blocks, natural column order)
 hipError_t launch_cast_tiled_w(const float* w, int rows, int cols, void* w16, int dtype, hipStream_t stream);
+// e4m3 operands (launch_gemm_fp8): the same question for the 128-byte K-tiles of the fp8 form, and the byte matrix -> tiled copy
+bool gemm_tiled_applies_f8(int64_t M, int N, int K);
+hipError_t launch_tile_bytes(const void* w8, int rows, int cols, void* out, hipStream_t stream);
 
 // row stride of the partial-sum buffer a launch writes: PATCH_SPLIT lands on token rows (images x (patches + 1) unless the
 // caller's buffer is laid out for more, e.g. rows padded to whole tiles); the other forms use their own M inside the kernel

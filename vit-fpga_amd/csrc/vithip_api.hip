@@ -310,6 +310,7 @@ int prepare_weights(vh_ctx* c) {
         HIPCHK(&c->err, launch_quantize_rows(P + o.ow, D, D, 1.0f, c->wo16[l], c->so[l], s));
         HIPCHK(&c->err, launch_fold_ln_f8(P + o.f1w, P + o.f1b, P + o.ln2w, P + o.ln2b, M, D, 1.0f, c->w1_16[l], c->s1[l], cd + 6 * D, cd + 6 * D + M, s));
         HIPCHK(&c->err, launch_quantize_rows(P + o.f2w, D, M, 1.0f, c->w2_16[l], c->s2[l], s));
+        if (c->h_tiled && c->w2t_16[l]) HIPCHK(&c->err, launch_tile_bytes(c->w2_16[l], D, M, c->w2t_16[l], s));   // the same bytes, tiled (h_tiled)
     }
     for (int l = 0; l < f.layers && c->fp8 && !c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
@@ -370,7 +371,7 @@ int prepare_weights(vh_ctx* c) {
     }
     HIPCHK(&c->err, hipStreamSynchronize(s));
     c->weights_ready = true;
-    c->weights_ready_tiled = c->h_tiled && !c->fp8;
+    c->weights_ready_tiled = c->h_tiled && (!c->fp8 || c->ln_fold);   // (e4m3 operands: prepared in the folded branch only)
     return VH_OK;
 }
 
@@ -523,11 +524,13 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
                       (size_t)L.NP * L.KP * esz >= 2 * ((size_t)D * esz + 256);
     // tiled hidden activation: both MLP GEMMs must take the persistent form (whole 256-row tiles, enough of them), the 16-bit split path
     const bool h_tiled = c->h_tiled && c->split && !c->fp8 && c->weights_ready_tiled && gemm_tiled_applies(rows_g, M, D) && gemm_tiled_applies(rows_g, D, M);
+    // e4m3 operands: the e4m3 hidden activation in the tiled layout of the e4m3 operand (fc1's epilogue writes it, fc2's DMA reads it)
+    const bool h_tiled8 = c->h_tiled && c->split && c->fp8 && c->weights_ready_tiled && gemm_tiled_applies_f8(rows_g, M, D) && gemm_tiled_applies_f8(rows_g, D, M);
     // the attention output likewise (16-bit ring forms -> the out-projection's tiled operand DMA); VH_ATT_TILED=0 keeps it row-major
     const bool att_tiled = h_tiled && c->att_tiled && gemm_tiled_applies(rows_g, D, D) && attention_tiled_applies(batch, T, f.heads) && !tail;
     // q|k|v head-major between the projection's epilogue and attention's operand DMA (same condition + the persistent form for N = 3 D)
     const bool qkv_hm = att_tiled && c->qkv_hm && gemm_tiled_applies(rows_g, 3 * D, D);
-    c->last_h_tiled = h_tiled && nl > 0 && c->ln_fold;
+    c->last_h_tiled = (h_tiled || h_tiled8) && nl > 0 && c->ln_fold;
     c->last_qkv_hm = qkv_hm && nl > 0 && c->ln_fold;
     for (int l = 0; l < nl && c->ln_fold; ++l) {
         const LayerOff& o = L.layer[l];
@@ -598,6 +601,10 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
             GemmArgs g1{xn16, c->w1_16[l], cd + 6 * D + M, h16, rows_g, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0, dt16, 0};
             g1.stats = stats_p; g1.out_tiled = 1;
             HIPCHK(&c->err, launch_gemm(g1, s));
+        } else if (h_tiled8) {
+            GemmArgs g1{xn16, c->w1_16[l], cd + 6 * D + M, h16, rows_g, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0, VH_DTYPE_FP8, 0};
+            g1.stats = stats_p; g1.wscale = s1; g1.out_tiled = 1;
+            HIPCHK(&c->err, launch_gemm_fp8(g1, s));
         } else
         HIPCHK(&c->err, gemm(xn16, c->w1_16[l], cd + 6 * D + M, h16, rows_g, M, D, VH_EPI_LNFOLD_GELU, cd + 6 * D, 0, s1));
         if ((rc = tmark(ST_FC1))) return rc;
@@ -607,6 +614,10 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
             GemmArgs g2{h16, c->w2t_16[l], P + o.f2b, xn16, rows_g, D, M, VH_EPI_RESID_SPLIT, nullptr, 0, dt16, 0};
             g2.out16 = xlo16; g2.partials = partials_p; g2.ab_tiled = 1;
             HIPCHK(&c->err, launch_gemm(g2, s));
+        } else if (h_tiled8) {
+            GemmArgs g2{h16, c->w2t_16[l], P + o.f2b, xn16, rows_g, D, M, VH_EPI_RESID_SPLIT, s2, 0, VH_DTYPE_FP8, 0};   // (`aux` = the weight scales)
+            g2.out16 = xlo16; g2.partials = partials_p; g2.ab_tiled = 1;
+            HIPCHK(&c->err, launch_gemm_fp8(g2, s));
         } else
         if (c->split) HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, xn16, rows_g, D, M, VH_EPI_RESID_SPLIT, nullptr, 0, s2));
         else HIPCHK(&c->err, gemm(h16, c->w2_16[l], P + o.f2b, x, rows_g, D, M, l + 1 < nl ? VH_EPI_RESID_LN : VH_EPI_BIAS_RESID, nullptr, 0, s2));
@@ -961,10 +972,12 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     auto carve16 = [&](size_t elems) { size_t o = w16_bytes; w16_bytes += align_up(elems * 2, 256); return o; };
     const size_t o_wp = carve16(D * L.KP);
     std::vector<size_t> o_qkv(cfg->layers), o_o(cfg->layers), o_1(cfg->layers), o_2(cfg->layers), o_2t(cfg->layers);
-    const bool want_tiled = cfg->dtype != VH_DTYPE_FP8 && D % 256 == 0 && M % 256 == 0 && !(getenv("VH_H_TILED") && getenv("VH_H_TILED")[0] == '0');
+    const bool want_tiled_any = D % 256 == 0 && M % 256 == 0 && !(getenv("VH_H_TILED") && getenv("VH_H_TILED")[0] == '0');
+    const bool want_tiled = cfg->dtype != VH_DTYPE_FP8 && want_tiled_any;
+    const bool want_tiled8 = cfg->dtype == VH_DTYPE_FP8 && want_tiled_any;   // e4m3 operands: fc2's weights (bytes) in the tiled e4m3 layout
     for (int l = 0; l < cfg->layers; ++l) {
         o_qkv[l] = carve16(3 * D * D); o_o[l] = carve16(D * D); o_1[l] = carve16(M * D); o_2[l] = carve16(D * M);
-        o_2t[l] = want_tiled ? carve16(D * M) : 0;
+        o_2t[l] = want_tiled ? carve16(D * M) : want_tiled8 ? carve16((D * M + 1) / 2) : 0;
     }
     std::vector<size_t> o_ot(cfg->layers);
     for (int l = 0; l < cfg->layers; ++l) o_ot[l] = want_tiled ? carve16(D * D) : 0;
@@ -994,7 +1007,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         c->ln_fold_cfg = c->ln_fold;
         c->split_cfg = c->split;
         c->cls_tail = (cfg->flags & VH_FLAG_CLS_TAIL) != 0;
-        c->h_tiled = want_tiled;
+        c->h_tiled = want_tiled || want_tiled8;
         { const char* e = getenv("VH_ATT_TILED"); c->att_tiled = !(e && e[0] == '0'); }
         { const char* e = getenv("VH_QKV_HM"); c->qkv_hm = !(e && e[0] == '0'); }
         const char* pf = getenv("VH_PATCH_FUSED");
@@ -1012,7 +1025,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
     for (int l = 0; l < cfg->layers; ++l) {
         c->wqkv16.push_back(c->w16 + o_qkv[l]); c->wo16.push_back(c->w16 + o_o[l]);
         c->w1_16.push_back(c->w16 + o_1[l]); c->w2_16.push_back(c->w16 + o_2[l]);
-        c->w2t_16.push_back(want_tiled ? c->w16 + o_2t[l] : nullptr);
+        c->w2t_16.push_back(want_tiled || want_tiled8 ? c->w16 + o_2t[l] : nullptr);
         c->wot_16.push_back(want_tiled ? c->w16 + o_ot[l] : nullptr);
         if (c->fp8) {
             float* sc = (float*)(c->w16 + o_sc) + (size_t)l * sc_per_layer;
