@@ -355,15 +355,17 @@ def test_fp8_is_deterministic_batch_independent_and_rejects_bad_dims():
 def test_tiled_e4m3_hidden_activation_gives_the_same_bits_as_the_row_major_one(monkeypatch, batch):
     """Round 4: with e4m3 operands too, fc1's epilogue writes the (e4m3) hidden activation in the tiled layout of the e4m3 operand
     straight from its registers (a 4 x 4 dword transpose over the four 16-lane rows: two v_permlane32_swap, two v_permlane16_swap)
-    and fc2's operand DMA reads it and a tiled copy of its weight bytes.  Byte order inside every 16-byte chunk is the natural one, so
+    and fc2's operand DMA reads it and a tiled copy of its weight bytes; the attention kernel stores its e4m3 result in the same
+    layout for the out-projection (VH_ATT_TILED).  Byte order inside every 16-byte chunk is the natural one, so
     every MFMA sees the same k order: bit-identical logits (VH_H_TILED=0), on exact tiles and on rows padded to whole tiles; a batch
     too small for the persistent form takes the row-major path and gives the same bits again."""
     cfg = S.CONFIGS["vit_base"]
     px = cfg["image_size"] ** 2 * cfg["channels"]
     din, dout = vithip.DeviceBuffer(batch * px * 4), vithip.DeviceBuffer(batch * cfg["classes"] * 4)
     outs, used = [], []
-    for tiled in ("0", "1"):
+    for tiled, att in (("0", "1"), ("1", "0"), ("1", "1")):   # row-major; h tiled only; the attention output (e4m3, tiled for out-proj) as well
         monkeypatch.setenv("VH_H_TILED", tiled)
+        monkeypatch.setenv("VH_ATT_TILED", att)
         ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=batch)
         ctx.init_weights_seeded(0)
         ctx.fill_input_seeded(1, batch, din.ptr)
@@ -373,8 +375,8 @@ def test_tiled_e4m3_hidden_activation_gives_the_same_bits_as_the_row_major_one(m
         small = ctx.forward(din.to_numpy(np.float32, (batch, cfg["image_size"], cfg["image_size"], cfg["channels"]))[:2])
         assert int(ctx.debug_read(3, 1)[0]) == 0 and np.array_equal(small, outs[-1][:2])
         ctx.close()
-    assert used == [0, 1], used
-    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+    assert used == [0, 1, 1], used
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("epi", ["bias", "gelu", "resid"])

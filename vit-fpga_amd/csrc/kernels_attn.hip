@@ -712,7 +712,11 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
                 // e4m3 output (fp8 path): a lane's quad of a group is ONE dword; the same half exchange on a pair of groups
                 // leaves lanes 0-31 with the 8 bytes of group rg and lanes 32-63 with those of group rg + 1: 4 x 8 bytes per
                 // lane instead of 8 x 4 (round 4; NST follows)
-                typename TO::elem* const op = out + ((int64_t)b * tokens + (q < tokens ? q : tokens - 1)) * D + h * 64 + 8 * hl;
+                // row-major: row mrow, byte h * 64 + 8 * hl (+ 32 db + 8 rg); tiled (the e4m3 operand's layout, 16-byte chunks): the pair of
+                // groups (rg, rg + 1) IS chunk h * 4 + 2 db + rg / 2 of the row, its halves in lanes l and l + 32 -- the same 8-byte stores
+                const int64_t mrow = (int64_t)b * tokens + (q < tokens ? q : tokens - 1);
+                typename TO::elem* const op = OTILE ? out + ((mrow >> 4) * (D >> 4) + h * 4) * 256 + (mrow & 15) * 16 + 8 * hl
+                                                    : out + mrow * D + h * 64 + 8 * hl;
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const f32x16& o = db ? o1 : o0;
@@ -721,7 +725,7 @@ attention_ring_kernel(const typename T::elem* __restrict__ qkv, typename TO::ele
                         const uint32_t ga = pack4<TO>(o[4 * rg] * inv, o[4 * rg + 1] * inv, o[4 * rg + 2] * inv, o[4 * rg + 3] * inv);
                         const uint32_t gb = pack4<TO>(o[4 * rg + 4] * inv, o[4 * rg + 5] * inv, o[4 * rg + 6] * inv, o[4 * rg + 7] * inv);
                         const auto sx = __builtin_amdgcn_permlane32_swap(ga, gb, false, false);
-                        if (q < tokens) *(u32x2*)(op + 32 * db + 8 * rg) = u32x2{sx[0], sx[1]};
+                        if (q < tokens) *(u32x2*)(op + (OTILE ? (2 * db + (rg >> 1)) * 256 : 32 * db + 8 * rg)) = u32x2{sx[0], sx[1]};
                     }
                 }
             }
@@ -966,7 +970,8 @@ hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads,
                                       : launch_attn_t<FP16, FP16, true, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed, in_hm_rows);
     }
     if (out_tiled) {
-        if (dtype == VH_DTYPE_FP8 || !attention_tiled_applies(batch, tokens, heads)) return hipErrorInvalidValue;
+        if (!attention_tiled_applies(batch, tokens, heads)) return hipErrorInvalidValue;
+        if (dtype == VH_DTYPE_FP8) return launch_attn_t<BF16, E4M3, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed);   // (tiled e4m3: 16-byte chunks)
         return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16, BF16, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed)
                                       : launch_attn_t<FP16, FP16, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed);
     }

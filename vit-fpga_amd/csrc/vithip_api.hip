@@ -308,6 +308,7 @@ int prepare_weights(vh_ctx* c) {
         HIPCHK(&c->err, launch_fold_ln_f8(P + o.kw, P + o.kb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + dd, c->sqkv[l] + D, cd + D, cd + 4 * D, s));
         HIPCHK(&c->err, launch_fold_ln_f8(P + o.vw, P + o.vb, P + o.ln1w, P + o.ln1b, D, D, 1.0f, wq + 2 * dd, c->sqkv[l] + 2 * D, cd + 2 * D, cd + 5 * D, s));
         HIPCHK(&c->err, launch_quantize_rows(P + o.ow, D, D, 1.0f, c->wo16[l], c->so[l], s));
+        if (c->h_tiled && c->wot_16[l]) HIPCHK(&c->err, launch_tile_bytes(c->wo16[l], D, D, c->wot_16[l], s));   // (att_tiled)
         HIPCHK(&c->err, launch_fold_ln_f8(P + o.f1w, P + o.f1b, P + o.ln2w, P + o.ln2b, M, D, 1.0f, c->w1_16[l], c->s1[l], cd + 6 * D, cd + 6 * D + M, s));
         HIPCHK(&c->err, launch_quantize_rows(P + o.f2w, D, M, 1.0f, c->w2_16[l], c->s2[l], s));
         if (c->h_tiled && c->w2t_16[l]) HIPCHK(&c->err, launch_tile_bytes(c->w2_16[l], D, M, c->w2t_16[l], s));   // the same bytes, tiled (h_tiled)
@@ -528,6 +529,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     const bool h_tiled8 = c->h_tiled && c->split && c->fp8 && c->weights_ready_tiled && gemm_tiled_applies_f8(rows_g, M, D) && gemm_tiled_applies_f8(rows_g, D, M);
     // the attention output likewise (16-bit ring forms -> the out-projection's tiled operand DMA); VH_ATT_TILED=0 keeps it row-major
     const bool att_tiled = h_tiled && c->att_tiled && gemm_tiled_applies(rows_g, D, D) && attention_tiled_applies(batch, T, f.heads) && !tail;
+    const bool att_tiled8 = h_tiled8 && c->att_tiled && gemm_tiled_applies_f8(rows_g, D, D) && attention_tiled_applies(batch, T, f.heads);
     // q|k|v head-major between the projection's epilogue and attention's operand DMA (same condition + the persistent form for N = 3 D)
     const bool qkv_hm = att_tiled && c->qkv_hm && gemm_tiled_applies(rows_g, 3 * D, D);
     c->last_h_tiled = (h_tiled || h_tiled8) && nl > 0 && c->ln_fold;
@@ -580,7 +582,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
             return VH_OK;
         }
         if ((rc = tmark(ST_ATTN))) return rc;
-        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, tickets_part + l, s, true, att_tiled,
+        HIPCHK(&c->err, launch_attention(qkv16, batch, T, f.heads, att16, c->fp8 ? VH_DTYPE_FP8 : dt16, tickets_part + l, s, true, att_tiled || att_tiled8,
                                          qkv_hm ? (int64_t)rows_g : 0));
         if ((rc = tmark(ST_ATTN))) return rc;
         if ((rc = mark(ST_ATTN))) return rc;
@@ -589,6 +591,10 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
             GemmArgs go{att16, c->wot_16[l], P + o.ob, xn16, rows_g, D, D, VH_EPI_RESID_SPLIT, nullptr, 0, dt16, 0};
             go.out16 = xlo16; go.partials = partials_p; go.ab_tiled = 1;
             HIPCHK(&c->err, launch_gemm(go, s));
+        } else if (att_tiled8) {
+            GemmArgs go{att16, c->wot_16[l], P + o.ob, xn16, rows_g, D, D, VH_EPI_RESID_SPLIT, so, 0, VH_DTYPE_FP8, 0};   // (`aux` = the weight scales)
+            go.out16 = xlo16; go.partials = partials_p; go.ab_tiled = 1;
+            HIPCHK(&c->err, launch_gemm_fp8(go, s));
         } else
         if (c->split) HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, xn16, rows_g, D, D, VH_EPI_RESID_SPLIT, nullptr, 0, so));
         else HIPCHK(&c->err, gemm(att16, c->wo16[l], P + o.ob, x, rows_g, D, D, VH_EPI_RESID_LN, nullptr, 0, so));
@@ -980,7 +986,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         o_2t[l] = want_tiled ? carve16(D * M) : want_tiled8 ? carve16((D * M + 1) / 2) : 0;
     }
     std::vector<size_t> o_ot(cfg->layers);
-    for (int l = 0; l < cfg->layers; ++l) o_ot[l] = want_tiled ? carve16(D * D) : 0;
+    for (int l = 0; l < cfg->layers; ++l) o_ot[l] = want_tiled ? carve16(D * D) : want_tiled8 ? carve16((D * D + 1) / 2) : 0;
     const size_t o_bqkv = w16_bytes;
     w16_bytes += align_up((size_t)cfg->layers * 3 * D * 4, 256);
     {
@@ -1026,7 +1032,7 @@ int vh_create(const vh_config* cfg, int device, vh_ctx** out) {
         c->wqkv16.push_back(c->w16 + o_qkv[l]); c->wo16.push_back(c->w16 + o_o[l]);
         c->w1_16.push_back(c->w16 + o_1[l]); c->w2_16.push_back(c->w16 + o_2[l]);
         c->w2t_16.push_back(want_tiled || want_tiled8 ? c->w16 + o_2t[l] : nullptr);
-        c->wot_16.push_back(want_tiled ? c->w16 + o_ot[l] : nullptr);
+        c->wot_16.push_back(want_tiled || want_tiled8 ? c->w16 + o_ot[l] : nullptr);
         if (c->fp8) {
             float* sc = (float*)(c->w16 + o_sc) + (size_t)l * sc_per_layer;
             c->sqkv.push_back(sc); c->so.push_back(sc + 3 * D); c->s1.push_back(sc + 4 * D); c->s2.push_back(sc + 4 * D + M);
