@@ -363,20 +363,22 @@ def test_tiled_e4m3_hidden_activation_gives_the_same_bits_as_the_row_major_one(m
     px = cfg["image_size"] ** 2 * cfg["channels"]
     din, dout = vithip.DeviceBuffer(batch * px * 4), vithip.DeviceBuffer(batch * cfg["classes"] * 4)
     outs, used = [], []
-    for tiled, att in (("0", "1"), ("1", "0"), ("1", "1")):   # row-major; h tiled only; the attention output (e4m3, tiled for out-proj) as well
+    # row-major; h tiled only; the attention output (e4m3, tiled for out-proj) as well; q|k|v (bf16) head-major as well (the default)
+    for tiled, att, hm in (("0", "1", "1"), ("1", "0", "1"), ("1", "1", "0"), ("1", "1", "1")):
         monkeypatch.setenv("VH_H_TILED", tiled)
         monkeypatch.setenv("VH_ATT_TILED", att)
+        monkeypatch.setenv("VH_QKV_HM", hm)
         ctx = vithip.VitContext(cfg, dtype=FP8, max_batch=batch)
         ctx.init_weights_seeded(0)
         ctx.fill_input_seeded(1, batch, din.ptr)
         ctx.forward_device(din.ptr, batch, dout.ptr)
         outs.append(dout.to_numpy(np.float32, (batch, cfg["classes"])))
-        used.append(int(ctx.debug_read(3, 1)[0]))
+        used.append((int(ctx.debug_read(3, 1)[0]), int(ctx.debug_read(4, 1)[0])))
         small = ctx.forward(din.to_numpy(np.float32, (batch, cfg["image_size"], cfg["image_size"], cfg["channels"]))[:2])
         assert int(ctx.debug_read(3, 1)[0]) == 0 and np.array_equal(small, outs[-1][:2])
         ctx.close()
-    assert used == [0, 1, 1], used
-    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert used == [(0, 0), (1, 0), (1, 0), (1, 1)], used
+    assert np.isfinite(outs[0]).all() and all(np.array_equal(outs[0], o) for o in outs[1:])
 
 
 @pytest.mark.parametrize("epi", ["bias", "gelu", "resid"])

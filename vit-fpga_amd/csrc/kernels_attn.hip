@@ -965,7 +965,8 @@ hipError_t launch_attention(const void* qkv16, int batch, int tokens, int heads,
     if (batch <= 0 || tokens <= 0 || heads <= 0) return hipErrorInvalidValue;
     if (in_hm_rows) {   // head-major q|k|v [3][heads][in_hm_rows][64] (the persistent projection's layout): ring forms with the tiled output only
         if (!out_tiled || in_hm_rows < (int64_t)batch * tokens || in_hm_rows * heads * 64 * 4 >= (1ll << 32)) return hipErrorInvalidValue;
-        if (dtype == VH_DTYPE_FP8 || !attention_tiled_applies(batch, tokens, heads)) return hipErrorInvalidValue;
+        if (!attention_tiled_applies(batch, tokens, heads)) return hipErrorInvalidValue;
+        if (dtype == VH_DTYPE_FP8) return launch_attn_t<BF16, E4M3, true, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed, in_hm_rows);
         return dtype == VH_DTYPE_BF16 ? launch_attn_t<BF16, BF16, true, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed, in_hm_rows)
                                       : launch_attn_t<FP16, FP16, true, true>(qkv16, batch, tokens, heads, out16, ticket, s, ticket_zeroed, in_hm_rows);
     }

@@ -579,8 +579,8 @@ static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
             if (!num_cu) return hipErrorUnknown;
             const int nfull = full_m * tiles_n;
             // (LNFOLD / BIAS with out_tiled: the q|k|v projection's HEAD-MAJOR result, gemm_epilogue.h)
-            // (e4m3 operands: the GELU forms write the tiled e4m3 hidden activation, RESID_SPLIT reads it; no head-major q|k|v there)
-            if constexpr (F8 ? (EPI == VH_EPI_LNFOLD_GELU || EPI == VH_EPI_BIAS_GELU) : (EPI == VH_EPI_LNFOLD_GELU || EPI == VH_EPI_BIAS_GELU || EPI == VH_EPI_LNFOLD || EPI == VH_EPI_BIAS)) {
+            // (e4m3 operands: the GELU forms write the tiled e4m3 hidden activation, RESID_SPLIT reads it; LNFOLD's bf16 q|k|v goes head-major like the 16-bit path's)
+            if constexpr (EPI == VH_EPI_LNFOLD_GELU || EPI == VH_EPI_BIAS_GELU || EPI == VH_EPI_LNFOLD || (!F8 && EPI == VH_EPI_BIAS)) {
                 if (g.out_tiled) return g.ab_tiled ? hipErrorInvalidValue : launch_pp_one<T, EPI, F8, true, 2, true, false>(g, nfull < num_cu ? nfull : num_cu, full_m, tiles_n, s);
             }
             if constexpr (F8 ? EPI == VH_EPI_RESID_SPLIT : (EPI == VH_EPI_RESID_SPLIT || EPI == VH_EPI_BIAS)) {

@@ -531,7 +531,7 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
     const bool att_tiled = h_tiled && c->att_tiled && gemm_tiled_applies(rows_g, D, D) && attention_tiled_applies(batch, T, f.heads) && !tail;
     const bool att_tiled8 = h_tiled8 && c->att_tiled && gemm_tiled_applies_f8(rows_g, D, D) && attention_tiled_applies(batch, T, f.heads);
     // q|k|v head-major between the projection's epilogue and attention's operand DMA (same condition + the persistent form for N = 3 D)
-    const bool qkv_hm = att_tiled && c->qkv_hm && gemm_tiled_applies(rows_g, 3 * D, D);
+    const bool qkv_hm = c->qkv_hm && ((att_tiled && gemm_tiled_applies(rows_g, 3 * D, D)) || (att_tiled8 && gemm_tiled_applies_f8(rows_g, 3 * D, D)));
     c->last_h_tiled = (h_tiled || h_tiled8) && nl > 0 && c->ln_fold;
     c->last_qkv_hm = qkv_hm && nl > 0 && c->ln_fold;
     for (int l = 0; l < nl && c->ln_fold; ++l) {
@@ -542,9 +542,9 @@ int enqueue_forward(vh_ctx* c, const float* in, int batch, float* logits, std::v
         const float *sq = c->fp8 ? c->sqkv[l] : nullptr, *so = c->fp8 ? c->so[l] : nullptr;
         const float *s1 = c->fp8 ? c->s1[l] : nullptr, *s2 = c->fp8 ? c->s2[l] : nullptr;
         if (qkv_hm) {
-            GemmArgs gq{xn16, c->wqkv16[l], cd + 3 * D, qkv16, rows_g, 3 * D, D, VH_EPI_LNFOLD, cd, 0, dt16, 0};
-            gq.stats = stats_p; gq.out_tiled = 1;
-            HIPCHK(&c->err, launch_gemm(gq, s));
+            GemmArgs gq{xn16, c->wqkv16[l], cd + 3 * D, qkv16, rows_g, 3 * D, D, VH_EPI_LNFOLD, cd, 0, c->fp8 ? VH_DTYPE_FP8 : dt16, 0};
+            gq.stats = stats_p; gq.out_tiled = 1; gq.wscale = sq;   // (e4m3 operands: the weight scales; null otherwise)
+            HIPCHK(&c->err, c->fp8 ? launch_gemm_fp8(gq, s) : launch_gemm(gq, s));
         } else
         HIPCHK(&c->err, gemm(xn16, c->wqkv16[l], cd + 3 * D, qkv16, rows_g, 3 * D, D, VH_EPI_LNFOLD, cd, 0, sq));
         if ((rc = tmark(ST_QKV))) return rc;
