@@ -239,20 +239,56 @@ __device__ __forceinline__ void gemm_epilogue_impl(const f32x4 (&acc)[MI][NI], c
 #endif
 // OTILED (16-bit GELU forms, full tiles): the result goes to the 16-ROW-BLOCKED layout of the MLP hidden activation (below) straight
 // from the registers, without the LDS transposition.
+// The LN-fold epilogues' constants out of the wave's staging slice, where the K loop's LDS-DMA put them (`cpre`): 8 rows' (mean, rstd)
+// at byte 8 r, d_n at 1024 + 4 n, c_n at 1280 + 4 n.  Inline asm: to the compiler an ordinary LDS read (or anything that may touch
+// memory) behind a pending LDS-DMA is a possible alias, which it answers with vmcnt(0) -- draining the next tile's operand DMAs, the
+// very wait this prefetch is there to avoid.  The K loop's counted waits retired these three DMAs K-tiles ago.
+__device__ __forceinline__ void epi_consts_from_lds(const char* sw, int frow, int fq, f32x4 (&bv)[4], f32x4 (&cv)[4], float2 (&lnst)[8]) {
+    const uint32_t la = (uint32_t)(uintptr_t)sw + (uint32_t)((fq * 4) * 4), lr = (uint32_t)(uintptr_t)sw + (uint32_t)(frow * 8);
+    asm volatile("ds_read_b128 %0, %8 offset:1024\n\tds_read_b128 %1, %8 offset:1088\n\tds_read_b128 %2, %8 offset:1152\n\tds_read_b128 %3, %8 offset:1216\n\t"
+                 "ds_read_b128 %4, %8 offset:1280\n\tds_read_b128 %5, %8 offset:1344\n\tds_read_b128 %6, %8 offset:1408\n\tds_read_b128 %7, %8 offset:1472"
+                 : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]), "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3]) : "v"(la));
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:128\n\tds_read_b64 %2, %8 offset:256\n\tds_read_b64 %3, %8 offset:384\n\t"
+                 "ds_read_b64 %4, %8 offset:512\n\tds_read_b64 %5, %8 offset:640\n\tds_read_b64 %6, %8 offset:768\n\tds_read_b64 %7, %8 offset:896\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(lnst[0]), "=&v"(lnst[1]), "=&v"(lnst[2]), "=&v"(lnst[3]), "=&v"(lnst[4]), "=&v"(lnst[5]), "=&v"(lnst[6]), "=&v"(lnst[7]) : "v"(lr));
+    // (the wait covers the b128 reads too: LDS operations return in order; their uses are tied to it here)
+    asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]));
+}
+
+// cpre (LN-fold forms of the persistent GEMM, round 4): the epilogue's constants -- the (mean, rstd) pairs of the wave's MI * 16 rows, d_n
+// and c_n of its 64 columns -- were put into the wave's staging slice `sw` by LDS-DMA during the K loop (kernels_gemm5.hip
+// issue_consts: rows at byte 8 r, d at 1024 + 4 n, c at 1280 + 4 n), so they come from LDS here instead of being loaded from global
+// memory behind the next tile's operand DMAs (a microsecond per tile before the first value could be computed).  They are read
+// into registers before the slice is used for staging.
 template <typename T, int EPI, int MI, int NI, int SMI = MI, bool MFULL = false, bool OTILED = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w,
-                                                     int lane, char* sw, int prio_grp = -1) {
+                                                     int lane, char* sw, int prio_grp = -1, bool cpre = false) {
     static_assert(NI == 4, "staged epilogue assumes a 64-column wave tile");
     static_assert(MI % SMI == 0 && SMI % 2 == 0, "slice must divide the wave tile");
     using elem = typename T::elem;
     const int M = e.M, N = e.N;
     const int frow = lane & 15, fq = lane >> 4;
     f32x4 bv[NI], cv[NI];
+    float2 lnst[epi_is_lnfold(EPI) ? MI : 1];   // LN-fold forms: (mean, rstd) of the lane's MI rows, all up front (read inside the row loop they
+                                                // would sit behind the previous pass's stores: one exposed load latency per pass)
+    bool have = false;
+    if constexpr (epi_is_lnfold(EPI) && MI == 8) { if (cpre) { epi_consts_from_lds(sw, frow, fq, bv, cv, lnst); have = true; } }   // (wave-uniform)
+    if (!have) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
-        if constexpr (epi_is_lnfold(EPI)) cv[ni] = *(const f32x4*)(e.aux + n_w + ni * 16 + fq * 4);
-        else cv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NI; ++ni) {
+            bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
+            if constexpr (epi_is_lnfold(EPI)) cv[ni] = *(const f32x4*)(e.aux + n_w + ni * 16 + fq * 4);
+            else cv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (epi_is_lnfold(EPI)) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int m = m_w + mi * 16 + frow;
+                if constexpr (!MFULL) m = m < M ? m : M - 1;
+                lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
+            }
+        }
     }
 
     if constexpr (epi_is_16bit(EPI) && (VH_EPI_ABL & 64)) {
@@ -270,11 +306,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
         // 16 (2j) + 8 h .. + 7 and those of the odd row beside it with 16 (2j + 1) + 8 h .. + 7 (h = fq >> 1): NATURAL column order
         // inside every chunk, so fc2 multiplies in the same k order as with a row-major h and the logits keep their bits.
         // h has exactly one consumer, fc2's operand DMA (kernels_gemm5.hip AT), which takes per-lane source addresses anyway.
-        float2 lnst[epi_is_lnfold(EPI) ? MI : 1];
-        if constexpr (epi_is_lnfold(EPI)) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)(m_w + mi * 16 + frow));
-        }
         char* const obase = (char*)e.out + ((int64_t)(m_w >> 4) * (N >> 3) + (n_w >> 3) + (fq & 1) * 2 + (fq >> 1)) * 256 + frow * 16;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -303,15 +334,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
         const int rr = lane >> 3, pc = lane & 7;
         // LNFOLD: the (mean, rstd) pairs of the lane's MI rows are loaded up front -- read inside the loop they sit behind
         // the previous pass's stores (possible alias), one exposed global-load latency per pass
-        float2 lnst[epi_is_lnfold(EPI) ? MI : 1];
-        if constexpr (epi_is_lnfold(EPI)) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                int m = m_w + mi * 16 + frow;
-                m = m < M ? m : M - 1;
-                lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
-            }
-        }
 #pragma unroll
         for (int h = 0; h < MI / SMI; ++h) {
             if constexpr (VH_EPI_PRIO == 1) {

@@ -63,6 +63,9 @@ namespace vh {
                         // SECOND accumulator set -- emulated in this loop: half the MFMAs (16 per compute phase), half the activation
                         // fragment reads, and 6 instead of 8 DMA pieces per wave and K-tile (the W operand is 128 rows: 2 pieces per wave)
 #endif
+#ifndef VH_PP_CPRE
+#define VH_PP_CPRE 1   // A/B: -DVH_PP_CPRE=0 loads the LN-fold epilogues' constants from global memory inside the epilogue
+#endif
 constexpr int kAblHalf = (VH_MAIN_ABL & 64) ? 1 : 0;
 constexpr int kWPieces = kAblHalf ? 2 : 4;   // DMA pieces of the W operand per wave and K-tile (the counted waits follow)
 // ---- DIAGNOSTIC BUILD ONLY (-DVH_DIAG_STAMPS -> libvithip_diag.so, tools/gemm_anatomy.py) ---------------------------
@@ -241,6 +244,10 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     const int wbase = wn * 8192;            // rows 64*wn ..    (inside a W stage)
 
     const int nk = (int)(row_bytes / KT_BYTES);
+    // constants of the LN-fold epilogues prefetched through LDS (16-bit persistent form; K-tile 1 must have a W(k+2) slot)
+    // (not with e4m3 operands: their K loop has no register to spare for the three DMA addresses -- 12 spills -- and their epilogue
+    //  starts with the weight-scale loads anyway)
+    const bool cpre = PERSIST && !F8 && epi_is_lnfold(EPI) && AST == 2 && nk >= 4 && VH_PP_CPRE;
 
     // ---- prologue of the first tile: K-tiles 0 and 1 ------------------------------------------------------------
     setup_tile(t);
@@ -292,9 +299,26 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
                 dma4(cur.a, cur.oa, smem + a_off(nk, 0) + dma_off);
             }
         };
+        // LN-fold forms (16-bit persistent): the epilogue's constants of THIS tile -- 128 (mean, rstd) pairs, 64 d_n, 64 c_n per wave --
+        // go into the wave's own staging slice by three more DMA instructions in L1 of K-tile 1 (the registers of the first
+        // weight fragments are free there), behind W(k+2): the two waits of that K-tile may leave three more operations in flight,
+        // every later wait finds them landed (gemm_epilogue.h `cpre`)
+        auto issue_consts = [&]() {
+            char* const slice = smem + 2 * STAGE_BYTES + wave * 4096;
+            const int m0 = tile_m * BM + grp * 128, n0 = tile_n * BN + wn * 64;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)((const char*)stats + ((int64_t)m0 * 8 + lane * 16)),
+                                             (void __attribute__((address_space(3)))*)slice, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(bias + n0 + lane),
+                                             (void __attribute__((address_space(3)))*)(slice + 1024), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(aux + n0 + lane),
+                                             (void __attribute__((address_space(3)))*)(slice + 1280), 4, 0, 0);
+        };
+        constexpr int kNC = 3;   // DMA instructions of issue_consts
         auto l1_issue_wait = [&](int kt) {
             if (kt + 2 < nk) {
                 issue_w(kt + 2);
+                if (cpre && kt == 1) { issue_consts(); pp_wait_vmcnt<4 + kWPieces + kNC>(); }
+                else
                 pp_wait_vmcnt<4 + kWPieces>();   // all but A(k+1) | W(k+2) (AST 3: A(k+2), W(k+2)) => W(k+1) landed
             } else if (has_next) {
                 if (kt + 2 == nk) {   // no W issue of this tile is left; the W base moves on to the next tile
@@ -312,6 +336,8 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         };
         auto c1_wait = [&](int kt) {
             if (AST == 2) {
+                if (cpre && kt == 1) pp_wait_vmcnt<kWPieces + kNC>();     // (+ the constant loads behind W(k+2))
+                else
                 if (kt + 2 < nk || has_next) pp_wait_vmcnt<kWPieces>();   // all but W(k+2) => A(k+1) landed
                 else pp_wait_vmcnt<0>();
             }
@@ -475,7 +501,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             else if constexpr (F8 && (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT))
                 gemm_epilogue_staged<E4M3, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
             else
-                gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true, OT>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE, epi_is_16bit(EPI) ? grp : -1);
+                gemm_epilogue_staged<T, EPI, MI, NI, VH_PP_SMI, true, OT>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE, epi_is_16bit(EPI) ? grp : -1, cpre);
         } else {
             if constexpr (F8 && epi_has_gelu(EPI))
                 gemm_epilogue8<EPI, MI, NI, VH_PP_SMI>(acc, e, m_w, n_w, lane_e, n_full, stage_epi, wave);
