@@ -75,6 +75,10 @@ constexpr int kWPieces = kAblHalf ? 2 : 4;   // DMA pieces of the W operand per 
 // CU.  The stamps go to a ring buffer of their own that nothing else reads; no output depends on them.  In the
 // product build (no VH_DIAG_STAMPS) none of this exists: no parameter, no instruction.
 #ifdef VH_DIAG_STAMPS
+#ifndef VH_DIAG_KT
+#define VH_DIAG_KT -1      // which K-tile of the stamped tile gets the phase stamps (-1: the middle one; -DVH_DIAG_KT=0: the first, behind the
+                           // previous tile's epilogue and its stores)
+#endif
 #ifndef VH_DIAG_REC_IT
 #define VH_DIAG_REC_IT 1   // which tile of a persistent workgroup is stamped (-DVH_DIAG_REC_IT=8: deep in the steady state)
 #endif
@@ -394,7 +398,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             const char* sa = smem + a_off(kt, k3) + xbase;
             const char* sw = smem + w_off(kt) + wbase;
 #ifdef VH_DIAG_STAMPS
-            unsigned long long* const pst_ = (first_tile_ && stamps && kt == nk / 2) ? stamps + ((size_t)blockIdx.x * 8 + wave) * 16 + 8 : nullptr;
+            unsigned long long* const pst_ = (first_tile_ && stamps && kt == (VH_DIAG_KT < 0 ? nk / 2 : VH_DIAG_KT)) ? stamps + ((size_t)blockIdx.x * 8 + wave) * 16 + 8 : nullptr;
 #endif
             VH_PSTAMP(0);
             // ---- L0 ------------------------------------------------------------------------------------------------
