@@ -15,6 +15,8 @@
 // chains: a0..a7 (accumulators), b, c (operands).  32-bit and 64-bit (packed fp32) variants.
 #define I_FMA32(i) "v_fma_f32 %" #i ", %8, %9, %" #i "\n\t"
 #define I_PKFMA32(i) "v_pk_fma_f32 %" #i ", %8, %9, %" #i "\n\t"
+#define I_PKFMA32_S(i) "v_pk_fma_f32 %" #i ", %8, %10, %" #i "\n\t"
+#define I_PKFMA32_CL(i) "v_pk_fma_f32 %" #i ", %8, %9, %" #i " clamp\n\t"
 #define I_PKFMA16(i) "v_pk_fma_f16 %" #i ", %8, %9, %" #i "\n\t"
 #define I_PKMUL16(i) "v_pk_mul_f16 %" #i ", %8, %" #i "\n\t"
 #define I_MED3(i) "v_med3_f32 %" #i ", %" #i ", %8, %9\n\t"
@@ -50,6 +52,8 @@ __global__ void __launch_bounds__(1024) probe(unsigned long long* out, float see
             if constexpr (KIND == 20) asm volatile(BODY4_C1(I_PKFMA32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
             if constexpr (KIND == 21) asm volatile(BODY4_C2(I_PKFMA32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
             if constexpr (KIND == 22) asm volatile(BODY4_C4(I_PKFMA32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            if constexpr (KIND == 23) { f32x2 sc = {0.5f, 0.25f}; asm volatile(BODY4(I_PKFMA32_S) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(sc)); }
+            if constexpr (KIND == 24) asm volatile(BODY4(I_PKFMA32_CL) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
             if constexpr (KIND == 10) asm volatile(BODY4(I_PKMUL32) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
         }
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -97,6 +101,8 @@ int main() {
     run<20>("v_pk_fma_f32, 1 chain", d);
     run<21>("v_pk_fma_f32, 2 chains", d);
     run<22>("v_pk_fma_f32, 4 chains", d);
+    run<23>("v_pk_fma_f32, SGPR pair", d);
+    run<24>("v_pk_fma_f32 clamp", d);
     run<9>("v_pk_add_f32", d);
     run<10>("v_pk_mul_f32", d);
     run<2>("v_pk_fma_f16", d);
