@@ -639,7 +639,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][NI], const 
 // contiguous memory per instruction, no LDS staging.
 template <int EPI, int MI, int NI, int SMI, bool MFULL = false, bool OTILED = false>
 __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const EpiArgs& e, int m_w, int n_w, int lane,
-                                               bool n_full, char* smem, int wave) {
+                                               bool n_full, char* smem, int wave, bool cpre = false) {
     static_assert(NI == 4 && MI % SMI == 0, "64-column wave tile");
     static_assert(EPI == VH_EPI_BIAS || EPI == VH_EPI_BIAS_GELU || EPI == VH_EPI_LNFOLD_GELU, "8-bit output: bias, bias+GELU or LN-fold+GELU");
     const int M = e.M, N = e.N;
@@ -652,19 +652,23 @@ __device__ __forceinline__ void gemm_epilogue8(const f32x4 (&acc)[MI][NI], const
     };
     if (n_full || epi_is_lnfold(EPI)) {   // LN fold: staged form only, N % tile == 0 guaranteed
         f32x4 bv[NI], cv[NI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
-            if constexpr (epi_is_lnfold(EPI)) cv[ni] = *(const f32x4*)(e.aux + n_w + ni * 16 + fq * 4);
-            else cv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
         float2 lnst[epi_is_lnfold(EPI) ? MI : 1];
-        if constexpr (epi_is_lnfold(EPI)) {
+        bool have = false;
+        if constexpr (epi_is_lnfold(EPI) && MI == 8) { if (cpre) { epi_consts_from_lds(smem + wave * (SMI * 16 * 128), frow, fq, bv, cv, lnst); have = true; } }   // (wave-uniform)
+        if (!have) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                int m = m_w + mi * 16 + frow;
-                m = m < M ? m : M - 1;
-                lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
+            for (int ni = 0; ni < NI; ++ni) {
+                bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
+                if constexpr (epi_is_lnfold(EPI)) cv[ni] = *(const f32x4*)(e.aux + n_w + ni * 16 + fq * 4);
+                else cv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if constexpr (epi_is_lnfold(EPI)) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    int m = m_w + mi * 16 + frow;
+                    m = m < M ? m : M - 1;
+                    lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
+                }
             }
         }
         if constexpr (OTILED && MFULL) {

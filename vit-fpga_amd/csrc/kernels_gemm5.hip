@@ -248,10 +248,9 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     const int wbase = wn * 8192;            // rows 64*wn ..    (inside a W stage)
 
     const int nk = (int)(row_bytes / KT_BYTES);
-    // constants of the LN-fold epilogues prefetched through LDS (16-bit persistent form; K-tile 1 must have a W(k+2) slot)
-    // (not with e4m3 operands: their K loop has no register to spare for the three DMA addresses -- 12 spills -- and their epilogue
-    //  starts with the weight-scale loads anyway)
-    const bool cpre = PERSIST && !F8 && epi_is_lnfold(EPI) && AST == 2 && nk >= 4 && VH_PP_CPRE;
+    // constants of the LN-fold epilogues prefetched through LDS (persistent form; K-tile 1 must have a W(k+2) slot)
+    // (not fc1 with e4m3 operands: that instantiation sits at 256 registers and the prefetch's extra live values spill into the K loop)
+    const bool cpre = PERSIST && epi_is_lnfold(EPI) && !(F8 && EPI == VH_EPI_LNFOLD_GELU) && AST == 2 && nk >= 4 && VH_PP_CPRE;
 
     // ---- prologue of the first tile: K-tiles 0 and 1 ------------------------------------------------------------
     setup_tile(t);
@@ -310,6 +309,18 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
         auto issue_consts = [&]() {
             char* const slice = smem + 2 * STAGE_BYTES + wave * 4096;
             const int m0 = tile_m * BM + grp * 128, n0 = tile_n * BN + wn * 64;
+            if constexpr (F8) {
+                // e4m3 operands: the K loop has no register for three 64-bit address pairs (they spilled 12): scalar bases + ONE
+                // per-lane offset register through the asm helpers; the weight scales of the 64 columns travel too (kNC = 4)
+                const uint32_t la = (uint32_t)(uintptr_t)slice;
+                uint32_t l4 = (uint32_t)lane * 4u;
+                asm_lds_dma4(bias + n0, l4, la + 1024);
+                asm_lds_dma4(aux + n0, l4, la + 1280);
+                asm_lds_dma4(wscale + n0, l4, la + 1536);
+                l4 *= 4u;
+                asm_lds_dma16((const char*)stats + (int64_t)m0 * 8, l4, la);
+                return;
+            }
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)((const char*)stats + ((int64_t)m0 * 8 + lane * 16)),
                                              (void __attribute__((address_space(3)))*)slice, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(bias + n0 + lane),
@@ -317,7 +328,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(aux + n0 + lane),
                                              (void __attribute__((address_space(3)))*)(slice + 1280), 4, 0, 0);
         };
-        constexpr int kNC = 3;   // DMA instructions of issue_consts
+        constexpr int kNC = F8 ? 4 : 3;   // DMA instructions of issue_consts
         auto l1_issue_wait = [&](int kt) {
             if (kt + 2 < nk) {
                 issue_w(kt + 2);
@@ -483,12 +494,23 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // produces the same bits, whatever the compiler's inlining context makes of the two statements.
 #pragma clang fp contract(off)
             const int fq_e = lane_e >> 4;
+            f32x4 wsv[NI];
+            if (cpre) {   // (wave-uniform) prefetched beside the other constants; gemm_epilogue.h epi_consts_from_lds says why this is asm
+                const uint32_t la = (uint32_t)(uintptr_t)(smem + 2 * STAGE_BYTES + wave * 4096) + (uint32_t)(fq_e * 16);
+                static_assert(NI == 4, "64-column wave tile");
+                asm volatile("ds_read_b128 %0, %4 offset:1536\n\tds_read_b128 %1, %4 offset:1600\n\tds_read_b128 %2, %4 offset:1664\n\tds_read_b128 %3, %4 offset:1728\n\t"
+                             "s_waitcnt lgkmcnt(0)" : "=&v"(wsv[0]), "=&v"(wsv[1]), "=&v"(wsv[2]), "=&v"(wsv[3]) : "v"(la));
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = n_w + ni * 16 + fq_e * 4;
+                    wsv[ni] = n < N ? *(const f32x4*)(wscale + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                const int n = n_w + ni * 16 + fq_e * 4;
-                const f32x4 ws = n < N ? *(const f32x4*)(wscale + n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = acc[mi][ni] * ws;
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = acc[mi][ni] * wsv[ni];
             }
         }
         if constexpr (PERSIST) {
@@ -501,7 +523,7 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
             // fp8 operands: GELU results leave as e4m3 (the next GEMM's A operand); RESID_LN writes an e4m3 copy of the rows, RESID_SPLIT
             // keeps the residual itself as an e4m3 plane (that operand) + a bf16 plane
             if constexpr (F8 && epi_has_gelu(EPI))
-                gemm_epilogue8<EPI, MI, NI, VH_PP_SMI, true, OT>(acc, e, m_w, n_w, lane_e, true, stage_epi, wave);
+                gemm_epilogue8<EPI, MI, NI, VH_PP_SMI, true, OT>(acc, e, m_w, n_w, lane_e, true, stage_epi, wave, cpre);
             else if constexpr (F8 && (EPI == VH_EPI_RESID_LN || EPI == VH_EPI_RESID_SPLIT))
                 gemm_epilogue_staged<E4M3, EPI, MI, NI, VH_PP_SMI, true>(acc, e, m_w, n_w, lane_e, stage_epi + wave * SLICE);
             else

@@ -143,6 +143,11 @@ __device__ __forceinline__ void asm_lds_dma16(const void* base, uint32_t lane_of
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2"
                  :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory", "m0");
 }
+// The same with 4 bytes per lane: 64 lanes x 4 B from `base + lane_off` -> 256 B at `lds_addr`.
+__device__ __forceinline__ void asm_lds_dma4(const void* base, uint32_t lane_off, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dword %1, %2"
+                 :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory", "m0");
+}
 // Returning atomic add on the wave-uniform address `base`, ISSUE only: `ret` is written when the operation completes,
 // i.e. the caller waits (vmcnt) before the first use of `ret` and keeps `ret`'s register untouched until then (the
 // attention work queue draws its ticket this way, one lane active).
