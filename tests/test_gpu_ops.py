@@ -523,9 +523,10 @@ def test_gemm_persistent_walks_several_tiles_per_workgroup(dt, epi):
     """The persistent ping-pong form (variant 6, the default for 16-bit results): with more tiles than CUs a workgroup
     runs 2-3 tiles back to back, prefetching the next tile's first K-tile from inside the epilogue.  Same arithmetic in
     the same order as the one-tile-per-workgroup form (variant 5), so the results must be bit-identical to it; the
-    oracle pins both.  Ragged M, K = 3 K-tiles / 1 K-tile / 2 K-tiles."""
+    oracle pins both.  Ragged M, K = 3 K-tiles / 1 K-tile / 2 K-tiles / 5 K-tiles (from four K-tiles on, the LN-fold epilogues of
+    the persistent form get their constants -- row statistics, d, c -- through LDS-DMA during the K loop instead of loading them)."""
     rng = np.random.default_rng(7)
-    for M, N, K in ((256 * 141 + 37, 1024, 192), (256 * 70 + 5, 2048, 64), (256 * 67, 1280, 128)):
+    for M, N, K in ((256 * 141 + 37, 1024, 192), (256 * 70 + 5, 2048, 64), (256 * 67, 1280, 128), (256 * 72, 768, 320)):
         a = (rng.random((M, K), dtype=np.float32) * 2 - 1)
         w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
         b = (rng.standard_normal(N) * 0.1).astype(np.float32)
