@@ -407,7 +407,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
             for (int i = 0; i < NL; ++i) {
                 int m;
                 const int64_t off = where(h, i, m);
-                if (m < M && !(VH_EPI_ABL & 8)) { a[i].h = *(const u32x2*)(hi + off); a[i].l = *(const lvec8*)(lo + off); }
+                if ((MFULL || m < M) && !(VH_EPI_ABL & 8)) { a[i].h = *(const u32x2*)(hi + off); a[i].l = *(const lvec8*)(lo + off); }
                 else { a[i].h = u32x2{0u, 0u}; a[i].l = lvec8{}; }
             }
         };
@@ -429,7 +429,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 const f32x4 v1 = *(const f32x4*)(sw + r * 256 + (((2 * pc + 1) ^ (r & 15)) << 4));
                 int m;
                 const int64_t off = where(h, i, m);
-                const bool ok = m < M;
+                const bool ok = MFULL || m < M;
                 const Add8& a = xa[h & 1][i];
                 const f32x4 h0 = dec4(a.h[0]), h1 = dec4(a.h[1]);
                 float v[8];
@@ -496,7 +496,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                     a[i].p0 = *(const f32x4*)pr;
                     a[i].p1 = *(const f32x4*)(pr + 4);
                 } else {
-                    if (m < M && !(VH_EPI_ABL & 8)) { a[i].h = *(const vec8*)(hi + off); a[i].l = *(const u32x2*)(lo + off); }
+                    if ((MFULL || m < M) && !(VH_EPI_ABL & 8)) { a[i].h = *(const vec8*)(hi + off); a[i].l = *(const u32x2*)(lo + off); }
                     else { a[i].h = vec8{}; a[i].l = u32x2{0u, 0u}; }
                 }
             }
@@ -520,7 +520,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 int m, p;
                 int64_t orow;
                 const int64_t off = where(h, i, m, orow, p);
-                const bool ok = m < M;
+                const bool ok = MFULL || m < M;   // (whole tiles: no exec-mask branch around every access)
                 const Add& a = xa[h & 1][i];
                 float v[8], ln[8];
                 vec8 hn;
