@@ -272,9 +272,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
     f32x4 bv[NI], cv[NI];
     float2 lnst[epi_is_lnfold(EPI) ? MI : 1];   // LN-fold forms: (mean, rstd) of the lane's MI rows, all up front (read inside the row loop they
                                                 // would sit behind the previous pass's stores: one exposed load latency per pass)
-    bool have = false;
-    if constexpr (epi_is_lnfold(EPI) && MI == 8) { if (cpre) { epi_consts_from_lds(sw, frow, fq, bv, cv, lnst); have = true; } }   // (wave-uniform)
-    if (!have) {
+    auto consts_from_global = [&]() {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             bv[ni] = *(const f32x4*)(e.bias + n_w + ni * 16 + fq * 4);
@@ -289,6 +287,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4 (&acc)[MI][NI],
                 lnst[mi] = *(const float2*)(e.stats + 2 * (int64_t)m);
             }
         }
+    };
+    // (plain if / else: with a flag between the two paths the compiler sees a way from the global loads to the asm reads that
+    //  overwrite their registers, and guards it with vmcnt(0))
+    if constexpr (epi_is_lnfold(EPI) && MI == 8) {
+        if (cpre) epi_consts_from_lds(sw, frow, fq, bv, cv, lnst);   // (wave-uniform)
+        else consts_from_global();
+    } else {
+        consts_from_global();
     }
 
     if constexpr (epi_is_16bit(EPI) && (VH_EPI_ABL & 64)) {

@@ -194,13 +194,13 @@ int gemm_pick_variant(int64_t M, int N, int epilogue) {
     return t256 >= min_tiles ? gemm_pp_variant(epilogue) : 1;  // the 256x256 ping-pong kernel needs enough tiles for the 256 CUs
 }
 
-// the persistent ping-pong form runs (launch_pp): enough tiles for the ping-pong kernel, whole 256 x 256 tiles, at least two K-tiles
+// the persistent ping-pong form runs (launch_pp): enough tiles for the ping-pong kernel, whole 256 x 256 tiles, at least four K-tiles (the forms that prefetch their epilogue's first loads need a W(k+2) slot in K-tile 1)
 bool gemm_tiled_applies(int64_t M, int N, int K) {
-    return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K / 64 >= 2 && gemm_pick_variant(M, N, VH_EPI_BIAS) == 6;
+    return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K / 64 >= 4 && gemm_pick_variant(M, N, VH_EPI_BIAS) == 6;
 }
 
 bool gemm_tiled_applies_f8(int64_t M, int N, int K) {   // (launch_gemm_fp8 takes the persistent form whenever whole tiles allow it)
-    return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && K / 128 >= 2 && gemm_pp_variant(VH_EPI_BIAS) == 6;
+    return M > 0 && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && K / 128 >= 4 && gemm_pp_variant(VH_EPI_BIAS) == 6;
 }
 
 const char* gemm_check(const GemmArgs& g) {

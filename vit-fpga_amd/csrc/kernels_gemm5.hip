@@ -113,6 +113,15 @@ __device__ __forceinline__ unsigned long long diag_hwid() {
 #define VH_STAMP(i, expr) do { } while (0)
 #endif
 
+// which persistent instantiations prefetch their epilogue's constants through LDS-DMA (issue_consts): the LN-fold epilogues, except
+// fc1 with e4m3 operands (that instantiation sits at 256 registers and the extra live values spill into the K loop).  (The same for
+// the split-residual epilogue's bias and first-pass planes was built and measured: out-proj -0.8 %, fc2 +2.3 % -- the first wait for
+// an ordinary load then comes BEHIND the first pass's stores and, being vmcnt(0), waits for their acknowledgements too.  Removed.)
+template <int EPI, bool F8>
+__host__ __device__ constexpr bool pp_uses_cpre() {
+    return VH_PP_CPRE && epi_is_lnfold(EPI) && !(F8 && EPI == VH_EPI_LNFOLD_GELU);
+}
+
 template <int N>
 __device__ __forceinline__ void pp_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -248,9 +257,10 @@ gemm_nt_pp_kernel(const void* __restrict__ Av, const void* __restrict__ Wv,
     const int wbase = wn * 8192;            // rows 64*wn ..    (inside a W stage)
 
     const int nk = (int)(row_bytes / KT_BYTES);
-    // constants of the LN-fold epilogues prefetched through LDS (persistent form; K-tile 1 must have a W(k+2) slot)
-    // (not fc1 with e4m3 operands: that instantiation sits at 256 registers and the prefetch's extra live values spill into the K loop)
-    const bool cpre = PERSIST && epi_is_lnfold(EPI) && !(F8 && EPI == VH_EPI_LNFOLD_GELU) && AST == 2 && nk >= 4 && VH_PP_CPRE;
+    // Constants of the LN-fold epilogues prefetched through LDS (persistent form;
+    // K-tile 1 must have a W(k+2) slot: the launcher sends shapes with fewer than four K-tiles to the one-tile form).  A compile-time
+    // property of the instantiation, so that the epilogue has no second path whose loads the compiler would have to fence.
+    constexpr bool cpre = pp_uses_cpre<EPI, F8>() && PERSIST && AST == 2;
 
     // ---- prologue of the first tile: K-tiles 0 and 1 ------------------------------------------------------------
     setup_tile(t);
@@ -620,7 +630,7 @@ static hipError_t launch_pp(const GemmArgs& g, int mode, hipStream_t s) {
         // last row of tiles (M % 256 != 0) goes to the one-tile-per-workgroup form as a tile range behind it
         const int full_m = (int)(g.M / 256);
         const int nk = g.K / (F8 ? 128 : 64);
-        if (mode == 1 && (g.N % 256 != 0 || full_m == 0 || nk < 2)) mode = 0;
+        if (mode == 1 && (g.N % 256 != 0 || full_m == 0 || nk < (pp_uses_cpre<EPI, F8>() ? 4 : 2))) mode = 0;
         // A ragged last row of tiles would run as a second launch BEHIND the persistent one: one more tile time on 3-12
         // CUs while the rest idle (batch 128: fc2 2.74 ms per forward against 1.96 ms in the one-tile form).  The
         // persistent form gains ~3 %, so it is worth that only when forced (variant 6 asked for explicitly).
